@@ -1,0 +1,218 @@
+/*
+ * ccx.h -- C-ABI of libccx, the MI355X (gfx950) batched CollectiveCrossing step library.
+ *
+ * The reference (nima-siboni/collectivecrossing v0.1.3) has NO FFI: its hot path is the pure
+ * Python method CollectiveCrossingEnv.step (src/collectivecrossing/collectivecrossing.py:161-261)
+ * plus the strategy objects it calls.  Every entry point below names the reference function(s) it
+ * replaces (file:line relative to the reference root); INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; device pointers travel as void* / typed pointers.
+ *   - every function returns 0 (CCX_OK) or a negative ccx_status; ccx_last_error() returns the
+ *     message of the last failure on the calling thread.
+ *   - all array arguments are DEVICE pointers unless the name ends in _host.
+ *   - array layout is struct-of-arrays, ENV-MAJOR: index [e*N + a] for per-agent arrays ("[E][N]"),
+ *     agent slot a in 0..N-1, boarding agents first (a < num_boarding  <=> "boarding_{a}",
+ *     otherwise "exiting_{a-num_boarding}"), exactly the reference's dict insertion order
+ *     (collectivecrossing.py:101-150).
+ *   - a handle is bound to one device and one HIP stream; calls are asynchronous on that stream
+ *     unless stated otherwise; a handle is not thread-safe (neither is the reference env).
+ */
+#ifndef CCX_H
+#define CCX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCX_ABI_VERSION 1
+
+typedef enum ccx_status {
+    CCX_OK = 0,
+    CCX_EINVAL = -1,     /* bad argument / unsupported configuration            */
+    CCX_ENOMEM = -2,     /* device or host allocation failed                    */
+    CCX_EHIP = -3,       /* a HIP runtime call failed (message has the detail)  */
+    CCX_ENODEVICE = -4   /* no usable gfx950 device                             */
+} ccx_status;
+
+/* reward_configs.py registry names -> enum (rewards.py:186-191) */
+enum { CCX_REWARD_DEFAULT = 0, CCX_REWARD_SIMPLE_DISTANCE = 1, CCX_REWARD_BINARY = 2,
+       CCX_REWARD_CONSTANT_NEGATIVE = 3 };
+/* terminateds.py:86-89 */
+enum { CCX_TERM_INDIVIDUAL_AT_DESTINATION = 0, CCX_TERM_ALL_AT_DESTINATION = 1 };
+/* truncateds.py:99-102 ("custom" has the same arithmetic as "max_steps", truncateds.py:64-95) */
+enum { CCX_TRUNC_MAX_STEPS = 0 };
+
+/* action codes, actions.py:8-24; CCX_ACTION_ABSENT = agent not in action_dict (it does not move,
+ * collectivecrossing.py:197-202 only iterates over the dict's items) */
+enum { CCX_ACTION_RIGHT = 0, CCX_ACTION_UP = 1, CCX_ACTION_LEFT = 2, CCX_ACTION_DOWN = 3,
+       CCX_ACTION_WAIT = 4, CCX_ACTION_ABSENT = 255 };
+
+/*
+ * Lowered, POD form of CollectiveCrossingConfig (configs.py:15-77) + the four strategy configs.
+ * Geometry is ABSOLUTE (already passed through utils/geometry.py:34-40):
+ *   tram_left = width/2 - tram_length/2, tram_right = width/2 + tram_length/2,
+ *   door_left/right = tram_left + cfg.tram_door_left/right.
+ */
+typedef struct ccx_params {
+    int32_t width, height, division_y;
+    int32_t tram_left, tram_right, door_left, door_right;
+    int32_t num_boarding, num_exiting;
+    int32_t boarding_dest_y, exiting_dest_y;
+    int32_t reward_mode, terminated_mode, truncated_mode;
+    int32_t max_steps;
+    int32_t _pad0;
+    /* DefaultRewardConfig (reward_configs.py:24-57); distance_penalty_factor is shared with
+     * SimpleDistanceRewardConfig (reward_configs.py:60-77) */
+    double boarding_destination_reward, tram_door_reward, tram_area_reward, distance_penalty_factor;
+    /* BinaryRewardConfig (reward_configs.py:80-101), ConstantNegativeRewardConfig (:104-121) */
+    double goal_reward, no_goal_reward, step_penalty;
+} ccx_params;
+
+/* per-agent result byte of one step ("agent_flags", u8 [E][N]) */
+#define CCX_AF_TERMINATED   0x01u /* terminateds[id] (always present, terminateds.py:40-82)             */
+#define CCX_AF_TRUNCATED    0x02u /* truncateds[id]; meaningful only with CCX_AF_LIVE (truncateds.py:56)  */
+#define CCX_AF_LIVE         0x04u /* agent was neither terminated nor truncated BEFORE this step:         */
+                                  /*   rewards[id] and truncateds[id] exist (rewards.py:64, truncateds.py:56) */
+#define CCX_AF_OBS          0x08u /* observations[id]/infos[id] emitted (collectivecrossing.py:243-254)   */
+#define CCX_AF_IN_TRAM_AREA 0x10u /* infos[id]["in_tram_area"]   (collectivecrossing.py:551-554)          */
+#define CCX_AF_AT_DOOR      0x20u /* infos[id]["at_door"]        (collectivecrossing.py:556-563)          */
+#define CCX_AF_ACTIVE       0x40u /* infos[id]["active"]                                                  */
+#define CCX_AF_AT_DEST      0x80u /* infos[id]["at_destination"] (collectivecrossing.py:663-683)          */
+
+/* per-env result byte of one step ("env_flags", u8 [E]) */
+#define CCX_EF_ALL_TERMINATED 0x01u /* terminateds["__all__"] (collectivecrossing.py:256,258) */
+#define CCX_EF_ALL_TRUNCATED  0x02u /* truncateds["__all__"]  (collectivecrossing.py:257,259) */
+#define CCX_EF_RESET          0x04u /* rollout only: the env was auto-reset after this step    */
+
+/* SoA state of the batch: the Agent dataclass (types.py:16-83) + env._step_count. */
+typedef struct ccx_state {
+    int32_t* x;           /* [E][N] */
+    int32_t* y;           /* [E][N] */
+    uint8_t* active;      /* [E][N] Agent.active      */
+    uint8_t* terminated;  /* [E][N] Agent.terminated  */
+    uint8_t* truncated;   /* [E][N] Agent.truncated   */
+    int32_t* step_count;  /* [E]    env._step_count   */
+    int32_t* episode;     /* [E]    number of auto-resets so far (selects the reset-pool entry) */
+} ccx_state;
+
+/* outputs of one step for the whole batch; any pointer may be NULL to skip that output */
+typedef struct ccx_step_out {
+    float*   obs;          /* [E][N][L], L = 6 + 4N, DefaultObservation (observations.py:43-94) */
+    double*  reward;       /* [E][N] f64, meaningful where CCX_AF_LIVE (rewards.py:44-182)      */
+    uint8_t* agent_flags;  /* [E][N] CCX_AF_*                                                   */
+    uint8_t* env_flags;    /* [E]    CCX_EF_*                                                   */
+} ccx_step_out;
+
+/* trajectory outputs of a K-step rollout; step s of env e lives at [s][e]...; NULL skips */
+typedef struct ccx_rollout_out {
+    float*   obs;          /* [K][E][N][L] */
+    double*  reward;       /* [K][E][N]    */
+    uint8_t* agent_flags;  /* [K][E][N]    */
+    uint8_t* env_flags;    /* [K][E]       */
+} ccx_rollout_out;
+
+/* device-side counters accumulated by ccx_rollout (u64 each; ccx_read_counters copies to host) */
+typedef struct ccx_counters {
+    uint64_t env_steps;        /* env-steps executed                                      */
+    uint64_t agent_steps;      /* env_steps * N (all slots)                               */
+    uint64_t live_agent_steps; /* agent-steps of agents with CCX_AF_LIVE                  */
+    uint64_t episodes;         /* auto-resets performed                                   */
+    uint64_t moves;            /* successful position changes (collectivecrossing.py:408) */
+    uint64_t arrivals;         /* deactivations (collectivecrossing.py:210-212)           */
+} ccx_counters;
+
+typedef struct ccx_handle ccx_handle;
+
+/* library / build info ------------------------------------------------------------------------ */
+int         ccx_abi_version(void);
+const char* ccx_build_info(void);      /* "libccx <ver> gfx950 hip <ver>" */
+const char* ccx_last_error(void);      /* thread-local message of the last failing call */
+
+/* observation length L = 2 + 4 + 4N (observations.py:113-118) */
+int32_t ccx_obs_len(int32_t num_agents);
+
+/*
+ * Create a batch of num_envs independent environments on `device`, using HIP stream `stream`
+ * (a hipStream_t passed as void*; NULL = the device's default stream).  env_offset is the global
+ * index of this handle's env 0 and total_envs the global batch size (multi-GPU sharding: the
+ * reset-pool entry of env e, episode j is (env_offset + e + j*total_envs) mod pool_size, so the
+ * trajectory of a global env does not depend on how many GPUs the batch is split over).
+ * Replaces CollectiveCrossingEnv.__init__ (collectivecrossing.py:44-89) for E instances.
+ * All agents start at (0,0), active, step_count 0: call ccx_set_state / ccx_reset_from_pool next.
+ */
+int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, int64_t total_envs,
+               int device, void* stream, ccx_handle** out);
+void ccx_destroy(ccx_handle* h);
+
+int32_t ccx_num_envs(const ccx_handle* h);
+int32_t ccx_num_agents(const ccx_handle* h);
+
+/* pointers to the handle's own device-resident SoA state (valid until ccx_destroy) */
+int ccx_state_view(ccx_handle* h, ccx_state* out);
+
+/*
+ * Overwrite / read back the state (tests reach into env._agents[...] the same way, e.g. the
+ * reference's test_collective_crossing.py:139-143).  Host pointers; NULL members are skipped.
+ * Synchronous.  set_state validates 0 <= x <= width, 0 <= y <= height (cells that exist,
+ * collectivecrossing.py:515) and flags in {0,1}.
+ */
+int ccx_set_state_host(ccx_handle* h, const ccx_state* src);
+int ccx_get_state_host(ccx_handle* h, ccx_state* dst);
+
+/*
+ * Reset pool: P seeded initial placements, u8 xy pairs [P][N][2], produced on the host by the
+ * reference's rejection-sampling reset (collectivecrossing.py:91-150) for seeds seed0..seed0+P-1.
+ * Device pointer; the library keeps the pointer (caller keeps the allocation alive).
+ */
+int ccx_set_reset_pool(ccx_handle* h, const uint8_t* pool_xy, int64_t pool_size);
+
+/* (Re)start every env whose mask byte is non-zero (mask NULL = all) from its pool entry for the
+ * env's current episode index; clears flags and step_count.  = reset() body :97-150 */
+int ccx_reset_from_pool(ccx_handle* h, const uint8_t* env_mask);
+
+/* DefaultObservation of the CURRENT state for every agent (what reset() returns, :153-159). */
+int ccx_observe(ccx_handle* h, float* obs /* [E][N][L] */);
+
+/*
+ * One step of every env = CollectiveCrossingEnv.step (collectivecrossing.py:161-261):
+ *   actions u8 [E][N] (CCX_ACTION_*), order u8 [E][N] or NULL: order[e][k] = slot of the agent
+ *   moved k-th (a permutation of 0..N-1; NULL = 0,1,..,N-1 = dict order of possible_agents).
+ */
+int ccx_step(ccx_handle* h, const uint8_t* actions, const uint8_t* order, const ccx_step_out* out);
+
+/*
+ * K fused steps in one launch (state stays in registers between steps).
+ *   actions u8 [K][E][N]; order u8 [K][E][N] or NULL.
+ *   auto_reset != 0: an env whose step raised terminateds["__all__"] or truncateds["__all__"] is
+ *   restarted from the reset pool before its next step (the rollout loop
+ *   `if done: env.reset(seed=...)` of the reference's demos, scripts/run_greedy_policy_demo.py:67-109).
+ *   out may be NULL (no trajectory); counters are accumulated into the handle.
+ */
+int ccx_rollout(ccx_handle* h, int32_t num_steps, const uint8_t* actions, const uint8_t* order,
+                int32_t auto_reset, const ccx_rollout_out* out);
+
+int ccx_zero_counters(ccx_handle* h);
+int ccx_read_counters(ccx_handle* h, ccx_counters* out_host);   /* synchronous */
+/* device pointer to the 6 u64 counters (for an RCCL all-reduce by the caller) */
+int ccx_counters_device_ptr(ccx_handle* h, uint64_t** out);
+
+/* timing of the most recent ccx_step / ccx_rollout launch, measured with HIP events recorded on
+ * the handle's stream around the kernel; synchronises on the stop event. */
+int ccx_last_launch_ms(ccx_handle* h, float* ms);
+
+/* launch-shape tuning (0 = library default): lanes of each 64-wide wavefront that carry agents
+ * (a multiple of the per-env lane group), and wavefronts per workgroup. */
+int ccx_set_launch_shape(ccx_handle* h, int32_t lanes_per_wave, int32_t waves_per_block);
+int ccx_get_launch_shape(ccx_handle* h, int32_t* lanes_per_wave, int32_t* waves_per_block,
+                         int32_t* group_lanes, int32_t* num_blocks);
+
+int ccx_synchronize(ccx_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCX_H */

@@ -1,0 +1,184 @@
+"""numpy front-end of the CPU oracle (``oracle/ccx_oracle.c``).
+
+TEST INFRASTRUCTURE ONLY -- see the header of ``ccx_oracle.c``.  Imported by ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg, never by the product package.
+The array contract is the one of ``include/ccx.h`` (env-major SoA), so a test can hand the same
+numpy arrays to the oracle and (through torch) to libccx and compare bit for bit.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from collectivecrossing_amd._abi import CcxCounters, CcxParams
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "_build" / "libccx_oracle.so"
+_lib = None
+
+
+def build(force: bool = False) -> Path:
+    """Compile the oracle with gcc (seconds)."""
+    src = _HERE / "ccx_oracle.c"
+    hdr = _HERE.parent / "include" / "ccx.h"
+    stale = (not _LIB_PATH.exists()) or _LIB_PATH.stat().st_mtime < max(
+        src.stat().st_mtime, hdr.stat().st_mtime)
+    if force or stale:
+        subprocess.run(["make", "-C", str(_HERE), "-s", "-B"], check=True)
+    return _LIB_PATH
+
+
+def _p(a: np.ndarray | None, dtype) -> C.c_void_p:
+    if a is None:
+        return C.c_void_p(None)
+    assert a.dtype == dtype and a.flags.c_contiguous, (a.dtype, dtype, a.flags)
+    return C.c_void_p(a.ctypes.data)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(str(_LIB_PATH))
+        PP = C.POINTER(CcxParams)
+        V = C.c_void_p
+        L.ccxo_tram_boundaries.argtypes = [C.c_int32] * 4 + [C.POINTER(C.c_int32 * 4)]
+        L.ccxo_tram_boundaries.restype = None
+        L.ccxo_obs_len.argtypes = [C.c_int32]
+        L.ccxo_obs_len.restype = C.c_int32
+        L.ccxo_is_valid_position.argtypes = [PP, C.c_int32, C.c_int32]
+        L.ccxo_is_valid_position.restype = C.c_int
+        L.ccxo_would_hit_tram_wall.argtypes = [PP, C.c_int32, C.c_int32]
+        L.ccxo_would_hit_tram_wall.restype = C.c_int
+        L.ccxo_reward.argtypes = [PP, C.c_int32, C.c_int32, C.c_int32]
+        L.ccxo_reward.restype = C.c_double
+        L.ccxo_observe.argtypes = [PP, C.c_int32, V, V, V, V]
+        L.ccxo_observe.restype = None
+        L.ccxo_reset_from_pool.argtypes = [PP, C.c_int32, C.c_int64, C.c_int64] + [V] * 8 + [V, C.c_int64]
+        L.ccxo_reset_from_pool.restype = None
+        L.ccxo_step.argtypes = [PP, C.c_int32] + [V] * 6 + [V, V] + [V] * 4 + [C.POINTER(CcxCounters)]
+        L.ccxo_step.restype = None
+        L.ccxo_rollout.argtypes = ([PP, C.c_int32, C.c_int64, C.c_int64] + [V] * 7 +
+                                   [C.c_int32, V, V, C.c_int32, V, C.c_int64] + [V] * 4 +
+                                   [C.POINTER(CcxCounters)])
+        L.ccxo_rollout.restype = None
+        _lib = L
+    return _lib
+
+
+def tram_boundaries(width: int, tram_length: int, door_left_rel: int, door_right_rel: int):
+    """(tram_left, tram_right, door_left, door_right), utils/geometry.py:20-47."""
+    out = (C.c_int32 * 4)()
+    lib().ccxo_tram_boundaries(width, tram_length, door_left_rel, door_right_rel, C.byref(out))
+    return tuple(int(v) for v in out)
+
+
+def is_valid_position(params: CcxParams, x: int, y: int) -> bool:
+    return bool(lib().ccxo_is_valid_position(C.byref(params), x, y))
+
+
+def would_hit_tram_wall(params: CcxParams, x: int, y: int) -> bool:
+    return bool(lib().ccxo_would_hit_tram_wall(C.byref(params), x, y))
+
+
+def reward(params: CcxParams, slot: int, x: int, y: int) -> float:
+    return float(lib().ccxo_reward(C.byref(params), slot, x, y))
+
+
+class OracleBatch:
+    """E independent envs stepped by the C oracle; mirrors the libccx handle's array contract."""
+
+    def __init__(self, params: CcxParams, num_envs: int, env_offset: int = 0,
+                 total_envs: int | None = None):
+        self.params = params
+        self.E = int(num_envs)
+        self.N = params.num_agents
+        self.L = 6 + 4 * self.N
+        self.env_offset = int(env_offset)
+        self.total_envs = int(total_envs if total_envs is not None else num_envs)
+        E, N = self.E, self.N
+        self.x = np.zeros((E, N), np.int32)
+        self.y = np.zeros((E, N), np.int32)
+        self.active = np.ones((E, N), np.uint8)
+        self.terminated = np.zeros((E, N), np.uint8)
+        self.truncated = np.zeros((E, N), np.uint8)
+        self.step_count = np.zeros((E,), np.int32)
+        self.episode = np.zeros((E,), np.int32)
+        self.pool: np.ndarray | None = None
+        self.counters = CcxCounters()
+
+    # -- state ------------------------------------------------------------------------------
+    def set_state(self, x=None, y=None, active=None, terminated=None, truncated=None,
+                  step_count=None, episode=None) -> None:
+        for name, val, dt in (("x", x, np.int32), ("y", y, np.int32), ("active", active, np.uint8),
+                              ("terminated", terminated, np.uint8),
+                              ("truncated", truncated, np.uint8),
+                              ("step_count", step_count, np.int32), ("episode", episode, np.int32)):
+            if val is not None:
+                getattr(self, name)[...] = np.asarray(val, dt).reshape(getattr(self, name).shape)
+
+    def set_reset_pool(self, pool_xy: np.ndarray) -> None:
+        pool_xy = np.ascontiguousarray(pool_xy, np.uint8)
+        assert pool_xy.ndim == 3 and pool_xy.shape[1:] == (self.N, 2), pool_xy.shape
+        self.pool = pool_xy
+
+    def reset_from_pool(self, env_mask: np.ndarray | None = None) -> None:
+        assert self.pool is not None
+        m = None if env_mask is None else np.ascontiguousarray(env_mask, np.uint8)
+        lib().ccxo_reset_from_pool(
+            C.byref(self.params), self.E, self.env_offset, self.total_envs,
+            _p(self.x, np.int32), _p(self.y, np.int32), _p(self.active, np.uint8),
+            _p(self.terminated, np.uint8), _p(self.truncated, np.uint8),
+            _p(self.step_count, np.int32), _p(self.episode, np.int32), _p(m, np.uint8),
+            _p(self.pool, np.uint8), len(self.pool))
+
+    # -- compute ----------------------------------------------------------------------------
+    def observe(self) -> np.ndarray:
+        obs = np.empty((self.E, self.N, self.L), np.float32)
+        lib().ccxo_observe(C.byref(self.params), self.E, _p(self.x, np.int32), _p(self.y, np.int32),
+                           _p(self.active, np.uint8), _p(obs, np.float32))
+        return obs
+
+    def step(self, actions: np.ndarray, order: np.ndarray | None = None, want_obs: bool = True):
+        E, N = self.E, self.N
+        actions = np.ascontiguousarray(actions, np.uint8).reshape(E, N)
+        order = None if order is None else np.ascontiguousarray(order, np.uint8).reshape(E, N)
+        obs = np.empty((E, N, self.L), np.float32) if want_obs else None
+        reward_ = np.empty((E, N), np.float64)
+        af = np.empty((E, N), np.uint8)
+        ef = np.empty((E,), np.uint8)
+        lib().ccxo_step(C.byref(self.params), E, _p(self.x, np.int32), _p(self.y, np.int32),
+                        _p(self.active, np.uint8), _p(self.terminated, np.uint8),
+                        _p(self.truncated, np.uint8), _p(self.step_count, np.int32),
+                        _p(actions, np.uint8), _p(order, np.uint8), _p(obs, np.float32),
+                        _p(reward_, np.float64), _p(af, np.uint8), _p(ef, np.uint8),
+                        C.byref(self.counters))
+        return obs, reward_, af, ef
+
+    def rollout(self, actions: np.ndarray, order: np.ndarray | None = None,
+                auto_reset: bool = False, want_obs: bool = True, want_traj: bool = True):
+        E, N = self.E, self.N
+        actions = np.ascontiguousarray(actions, np.uint8)
+        K = actions.shape[0]
+        assert actions.shape == (K, E, N), actions.shape
+        order = None if order is None else np.ascontiguousarray(order, np.uint8)
+        if auto_reset:
+            assert self.pool is not None, "auto_reset needs a reset pool"
+        obs = np.empty((K, E, N, self.L), np.float32) if (want_obs and want_traj) else None
+        reward_ = np.empty((K, E, N), np.float64) if want_traj else None
+        af = np.empty((K, E, N), np.uint8) if want_traj else None
+        ef = np.empty((K, E), np.uint8) if want_traj else None
+        pool = self.pool
+        lib().ccxo_rollout(C.byref(self.params), E, self.env_offset, self.total_envs,
+                           _p(self.x, np.int32), _p(self.y, np.int32), _p(self.active, np.uint8),
+                           _p(self.terminated, np.uint8), _p(self.truncated, np.uint8),
+                           _p(self.step_count, np.int32), _p(self.episode, np.int32), K,
+                           _p(actions, np.uint8), _p(order, np.uint8), int(bool(auto_reset)),
+                           _p(pool, np.uint8), 0 if pool is None else len(pool),
+                           _p(obs, np.float32), _p(reward_, np.float64), _p(af, np.uint8),
+                           _p(ef, np.uint8), C.byref(self.counters))
+        return obs, reward_, af, ef

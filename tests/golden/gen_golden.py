@@ -1,0 +1,434 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE in the build container.
+
+The reference (pure Python, /root/reference) is imported here and only here; it never travels to
+the GPU box.  Its module tops import ``gymnasium`` and ``ray`` which are not installed, so the
+tiny stand-ins of ``_refshim/`` (base classes + numpy seeding, see its README) go first on
+``sys.path``.  Before writing anything the script replays the reference's OWN committed goldens
+(seed 42) through the imported reference, which proves the stand-in seeding consumes the PCG64
+stream exactly like real gymnasium did when those goldens were recorded.
+
+Every fixture is DATA: the config, the initial state, the per-step inputs (actions, move order) and
+the reference's outputs re-encoded in the array contract of include/ccx.h:
+
+  config_json                       str   kwargs of CollectiveCrossingConfig (+ "_relaxed" flag)
+  init_{x,y}[E,N] i32, init_{active,terminated,truncated}[E,N] u8, init_step_count[E] i32
+  actions[K,E,N] u8 (255 = agent not in action_dict), order[K,E,N] u8 (dict iteration order)
+  x,y[K,E,N] i32; active,terminated,truncated[K,E,N] u8; step_count[K,E] i32   (post-step state)
+  reward[K,E,N] f64 (0 where not LIVE), agent_flags[K,E,N] u8, env_flags[K,E] u8
+  obs[K,E,N,L] f32 (DefaultObservation of every agent, from the reference's observation function)
+  (rollout fixtures also) pool_xy[P,N,2] u8 = reference reset(seed=seed0+p) placements, seed0
+
+Usage: python tests/golden/gen_golden.py            (no-op when /root/reference is absent)
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REF = Path(os.environ.get("CCX_REFERENCE", "/root/reference"))
+
+AF = dict(TERMINATED=1, TRUNCATED=2, LIVE=4, OBS=8, IN_TRAM=16, AT_DOOR=32, ACTIVE=64, AT_DEST=128)
+EF = dict(ALL_TERM=1, ALL_TRUNC=2, RESET=4)
+ABSENT = 255
+
+
+def import_reference():
+    sys.path.insert(0, str(REF / "src"))
+    sys.path.insert(0, str(HERE / "_refshim"))
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    import collectivecrossing as cc  # noqa: F401  (the reference)
+    from collectivecrossing import configs, observation_configs, reward_configs  # noqa: F401
+    from collectivecrossing import terminated_configs, truncated_configs  # noqa: F401
+    return cc
+
+
+def build_ref_config(cfg: dict):
+    """dict (our fixture format) -> reference CollectiveCrossingConfig."""
+    from collectivecrossing.configs import CollectiveCrossingConfig
+    from collectivecrossing.reward_configs import get_reward_config
+    from collectivecrossing.terminated_configs import get_terminated_config
+    from collectivecrossing.truncated_configs import get_truncated_config
+
+    kw = {k: v for k, v in cfg.items() if not k.endswith("_config") and not k.startswith("_")}
+    rc = dict(cfg.get("reward_config", {"reward_function": "default"}))
+    tc = dict(cfg.get("terminated_config", {"terminated_function": "individual_at_destination"}))
+    uc = dict(cfg.get("truncated_config", {"truncated_function": "max_steps"}))
+    kw["reward_config"] = get_reward_config(rc.pop("reward_function"), **rc)
+    kw["terminated_config"] = get_terminated_config(tc.pop("terminated_function"), **tc)
+    kw["truncated_config"] = get_truncated_config(uc.pop("truncated_function"), **uc)
+    if cfg.get("_relaxed"):
+        # reference-illegal agent counts (BASELINE config 5): bypass validation, SURVEY 8c
+        from collectivecrossing.observation_configs import DefaultObservationConfig
+        kw.setdefault("observation_config", DefaultObservationConfig())
+        kw.setdefault("render_mode", None)
+        return CollectiveCrossingConfig.model_construct(**kw)
+    return CollectiveCrossingConfig(**kw)
+
+
+def ids_of(cfg: dict) -> list[str]:
+    return ([f"boarding_{i}" for i in range(cfg["num_boarding_agents"])] +
+            [f"exiting_{j}" for j in range(cfg["num_exiting_agents"])])
+
+
+class Recorder:
+    """Drives E reference envs for K steps and re-encodes everything as arrays."""
+
+    def __init__(self, cfg: dict, E: int, K: int):
+        from collectivecrossing import CollectiveCrossingEnv
+        self.cfg, self.E, self.K = cfg, E, K
+        self.ids = ids_of(cfg)
+        self.N = N = len(self.ids)
+        self.L = 6 + 4 * N
+        self.envs = [CollectiveCrossingEnv(config=build_ref_config(cfg)) for _ in range(E)]
+        z = lambda *s, dt=np.uint8: np.zeros(s, dt)  # noqa: E731
+        self.a = dict(
+            init_x=z(E, N, dt=np.int32), init_y=z(E, N, dt=np.int32), init_active=z(E, N),
+            init_terminated=z(E, N), init_truncated=z(E, N), init_step_count=z(E, dt=np.int32),
+            actions=np.full((K, E, N), ABSENT, np.uint8), order=z(K, E, N),
+            x=z(K, E, N, dt=np.int32), y=z(K, E, N, dt=np.int32), active=z(K, E, N),
+            terminated=z(K, E, N), truncated=z(K, E, N), step_count=z(K, E, dt=np.int32),
+            reward=z(K, E, N, dt=np.float64), agent_flags=z(K, E, N), env_flags=z(K, E),
+            obs=z(K, E, N, self.L, dt=np.float32))
+
+    def snapshot_init(self, e: int) -> None:
+        env = self.envs[e]
+        for i, aid in enumerate(self.ids):
+            ag = env._agents[aid]
+            self.a["init_x"][e, i], self.a["init_y"][e, i] = int(ag.position[0]), int(ag.position[1])
+            self.a["init_active"][e, i] = ag.active
+            self.a["init_terminated"][e, i] = ag.terminated
+            self.a["init_truncated"][e, i] = ag.truncated
+        self.a["init_step_count"][e] = env._step_count
+
+    def step(self, s: int, e: int, action_dict: dict[str, int]) -> tuple[bool, bool]:
+        env, ids, a = self.envs[e], self.ids, self.a
+        slot = {aid: i for i, aid in enumerate(ids)}
+        # move order = dict iteration order; agents not in the dict fill the tail (they don't move)
+        listed = [slot[k] for k in action_dict]
+        a["order"][s, e] = listed + [i for i in range(self.N) if i not in listed]
+        for k, v in action_dict.items():
+            a["actions"][s, e, slot[k]] = v
+        obs, rew, term, trunc, infos = env.step(dict(action_dict))
+        for i, aid in enumerate(ids):
+            ag = env._agents[aid]
+            a["x"][s, e, i], a["y"][s, e, i] = int(ag.position[0]), int(ag.position[1])
+            a["active"][s, e, i] = ag.active
+            a["terminated"][s, e, i] = ag.terminated
+            a["truncated"][s, e, i] = ag.truncated
+            f = 0
+            assert aid in term, "terminateds lists every agent every step"
+            f |= AF["TERMINATED"] if term[aid] else 0
+            assert (aid in rew) == (aid in trunc)
+            if aid in rew:
+                f |= AF["LIVE"]
+                a["reward"][s, e, i] = float(rew[aid])
+                f |= AF["TRUNCATED"] if trunc[aid] else 0
+            assert (aid in obs) == (aid in infos)
+            if aid in obs:
+                f |= AF["OBS"]
+                info = infos[aid]
+                assert info["in_tram_area"] == env.is_in_tram_area(aid)
+                assert info["active"] == ag.active
+            f |= AF["IN_TRAM"] if env.is_in_tram_area(aid) else 0
+            f |= AF["AT_DOOR"] if env.is_at_tram_door(aid) else 0
+            f |= AF["ACTIVE"] if ag.active else 0
+            f |= AF["AT_DEST"] if env.has_agent_reached_destination(aid) else 0
+            a["agent_flags"][s, e, i] = f
+            full = env._get_agent_observation(aid)  # the reference's observation function
+            if aid in obs:
+                assert np.array_equal(full, obs[aid])
+            a["obs"][s, e, i] = full
+        a["step_count"][s, e] = env._step_count
+        at, au = bool(term["__all__"]), bool(trunc["__all__"])
+        a["env_flags"][s, e] = (EF["ALL_TERM"] if at else 0) | (EF["ALL_TRUNC"] if au else 0)
+        return at, au
+
+    def save(self, name: str, **extra) -> None:
+        out = HERE / f"{name}.npz"
+        np.savez_compressed(out, config_json=np.array(json.dumps(self.cfg)), **self.a, **extra)
+        print(f"wrote {out.name}: E={self.E} K={self.K} N={self.N} {out.stat().st_size / 1024:.0f} KiB")
+
+
+# ------------------------------------------------------------------------------------ configs
+def cfg_c1(**over):
+    """BASELINE config 1/2/4 geometry = the reference README quick-start (README.md:48-64)."""
+    c = dict(width=12, height=8, division_y=4, tram_door_left=5, tram_door_right=7, tram_length=9,
+             num_boarding_agents=5, num_exiting_agents=3, exiting_destination_area_y=0,
+             boarding_destination_area_y=8,
+             truncated_config=dict(truncated_function="max_steps", max_steps=100))
+    c.update(over)
+    return c
+
+
+def cfg_c3(**over):
+    """BASELINE config 3: 20x12, 16+16, SimpleDistance."""
+    c = dict(width=20, height=12, division_y=6, tram_door_left=6, tram_door_right=10,
+             tram_length=16, num_boarding_agents=16, num_exiting_agents=16,
+             exiting_destination_area_y=0, boarding_destination_area_y=12,
+             reward_config=dict(reward_function="simple_distance", distance_penalty_factor=0.1),
+             truncated_config=dict(truncated_function="max_steps", max_steps=100))
+    c.update(over)
+    return c
+
+
+def cfg_c5(nb, ne, max_steps=500, **over):
+    """BASELINE config 5: 32x16, AllAtDestination, MaxSteps; 32+32 is reference-illegal."""
+    c = dict(width=32, height=16, division_y=8, tram_door_left=10, tram_door_right=16,
+             tram_length=26, num_boarding_agents=nb, num_exiting_agents=ne,
+             exiting_destination_area_y=0, boarding_destination_area_y=16,
+             terminated_config=dict(terminated_function="all_at_destination"),
+             truncated_config=dict(truncated_function="max_steps", max_steps=max_steps))
+    if nb + ne > 50:
+        c["_relaxed"] = True
+    c.update(over)
+    return c
+
+
+def cfg_small(**over):
+    """The 10x6 / 2+1 env of the reference's VCR tests (test_trajectory_vcr.py:323-340)."""
+    c = dict(width=10, height=6, division_y=3, tram_door_left=3, tram_door_right=5, tram_length=8,
+             num_boarding_agents=2, num_exiting_agents=1, exiting_destination_area_y=0,
+             boarding_destination_area_y=5,
+             truncated_config=dict(truncated_function="max_steps", max_steps=50))
+    c.update(over)
+    return c
+
+
+# ------------------------------------------------------------------------------------ drivers
+def run_random(name, cfg, seeds, K, shuffle=False, p_absent=0.0, act_done=True):
+    """reset(seed=s) then K steps of uniform random actions (keeps stepping after __all__)."""
+    rec = Recorder(cfg, len(seeds), K)
+    for e, seed in enumerate(seeds):
+        env = rec.envs[e]
+        env.reset(seed=int(seed))
+        rec.snapshot_init(e)
+        rng = np.random.default_rng(1000 + int(seed))
+        for s in range(K):
+            ids = list(rec.ids) if act_done else list(env.agents)
+            if shuffle:
+                ids = [ids[i] for i in rng.permutation(len(ids))]
+            acts = {aid: int(rng.integers(0, 5)) for aid in ids if rng.random() >= p_absent}
+            rec.step(s, e, acts)
+    rec.save(name, seeds=np.asarray(seeds, np.int64))
+
+
+def run_greedy(name, cfg, seeds, K):
+    """reset(seed) then the reference's GreedyPolicy(epsilon=0) for live agents in index order."""
+    from baseline_policies import GreedyPolicy
+    rec = Recorder(cfg, len(seeds), K)
+    for e, seed in enumerate(seeds):
+        env = rec.envs[e]
+        obs, _ = env.reset(seed=int(seed))
+        rec.snapshot_init(e)
+        pol = GreedyPolicy(randomness_factor=0.0, seed=42)
+        for s in range(K):
+            acts = {aid: int(pol.get_action(aid, None, env)) for aid in env.agents}
+            rec.step(s, e, acts)
+    rec.save(name, seeds=np.asarray(seeds, np.int64))
+
+
+def run_scenarios(name, cfg, scenarios):
+    """Forced initial states (the reference's tests poke env._agents the same way)."""
+    K = max(len(sc["steps"]) for sc in scenarios)
+    rec = Recorder(cfg, len(scenarios), K)
+    for e, sc in enumerate(scenarios):
+        env = rec.envs[e]
+        env.reset(seed=0)
+        for aid, st in sc["state"].items():
+            ag = env._agents[aid]
+            ag.position = np.array(st["pos"], dtype=np.int32)
+            ag.active = bool(st.get("active", True))
+            ag.terminated = bool(st.get("terminated", False))
+            ag.truncated = bool(st.get("truncated", False))
+        env._step_count = int(sc.get("step_count", 0))
+        rec.snapshot_init(e)
+        steps = list(sc["steps"]) + [{}] * (K - len(sc["steps"]))
+        for s, acts in enumerate(steps):
+            rec.step(s, e, acts)
+    rec.save(name, labels=np.array([sc["label"] for sc in scenarios]))
+
+
+def run_rollout(name, cfg, E, K, P, seed0, total_envs=None, env_offset=0):
+    """Auto-reset rollout: `if __all__: reset(seed=seed0 + (g + episode*total) % P)`."""
+    from collectivecrossing import CollectiveCrossingEnv
+    total = total_envs or E
+    ids = ids_of(cfg)
+    N = len(ids)
+    pool = np.zeros((P, N, 2), np.uint8)
+    penv = CollectiveCrossingEnv(config=build_ref_config(cfg))
+    for pidx in range(P):
+        penv.reset(seed=seed0 + pidx)
+        for i, aid in enumerate(ids):
+            pool[pidx, i] = penv._agents[aid].position
+    rec = Recorder(cfg, E, K)
+    rng = np.random.default_rng(seed0)
+    all_actions = rng.integers(0, 5, size=(K, E, N), dtype=np.uint8)
+    episodes = np.zeros(E, np.int32)
+    for e in range(E):
+        env = rec.envs[e]
+        g = env_offset + e
+        env.reset(seed=seed0 + (g % P))
+        for i, aid in enumerate(ids):
+            assert tuple(env._agents[aid].position) == tuple(pool[g % P, i])
+        rec.snapshot_init(e)
+        for s in range(K):
+            acts = {aid: int(all_actions[s, e, i]) for i, aid in enumerate(ids)}
+            at, au = rec.step(s, e, acts)
+            if at or au:
+                episodes[e] += 1
+                env.reset(seed=seed0 + int((g + int(episodes[e]) * total) % P))
+                rec.a["env_flags"][s, e] |= EF["RESET"]
+    rec.save(name, pool_xy=pool, seed0=np.int64(seed0), final_episode=episodes,
+             total_envs=np.int64(total), env_offset=np.int64(env_offset))
+
+
+# --------------------------------------------------------------------------- shim validation
+def replay_reference_goldens():
+    """The reference's own goldens through the imported reference (validates the stand-ins)."""
+    from collectivecrossing import CollectiveCrossingEnv
+    for fn in ("golden_basic_trajectory.json", "regression_test.json"):
+        d = json.loads((REF / "tests/fixtures/trajectories/golden" / fn).read_text())
+        env = CollectiveCrossingEnv(config=build_ref_config(
+            {k: v for k, v in d["config"].items() if k != "render_mode"}))
+        obs, _ = env.reset(seed=42)
+        for k, v in d["initial_observations"].items():
+            assert np.array_equal(obs[k], np.asarray(v, np.float32)), (fn, "initial", k)
+        for st in d["steps"]:
+            obs, rew, term, trunc, _ = env.step(st["active_actions"])
+            for k, v in st["next_observations"].items():
+                assert np.array_equal(obs[k], np.asarray(v, np.float32)), (fn, st["step"], k)
+            for k, v in st["next_rewards"].items():
+                assert float(rew[k]) == v, (fn, st["step"], k, rew[k], v)
+            assert {k: bool(v) for k, v in term.items()} == st["next_terminated"]
+            assert {k: bool(v) for k, v in trunc.items()} == st["next_truncated"]
+        print(f"reference golden {fn}: replayed bit-exactly through the imported reference")
+
+
+def edge_scenarios():
+    """G5 edge probes on the 10x8 env used all over the reference's unit tests."""
+    cfg = dict(width=10, height=8, division_y=4, tram_door_left=3, tram_door_right=5,
+               tram_length=8, num_boarding_agents=2, num_exiting_agents=2,
+               exiting_destination_area_y=0, boarding_destination_area_y=8,
+               truncated_config=dict(truncated_function="max_steps", max_steps=6))
+    # geometry: tram 1..9, door 4..6 -> single passable door cell x=5
+    far = {"boarding_0": dict(pos=[0, 0]), "boarding_1": dict(pos=[9, 1]),
+           "exiting_0": dict(pos=[2, 6]), "exiting_1": dict(pos=[8, 6])}
+
+    def st(**kw):
+        s = {k: dict(v) for k, v in far.items()}
+        for k, v in kw.items():
+            s[k] = v
+        return s
+
+    R, U, Lf, D, Wt = 0, 1, 2, 3, 4
+    sc = [
+        dict(label="walk_to_x_eq_W", state=st(boarding_0=dict(pos=[8, 2])),
+             steps=[{"boarding_0": R}] * 4),
+        dict(label="walk_up_to_y_eq_H_through_door", state=st(boarding_0=dict(pos=[5, 3])),
+             steps=[{"boarding_0": U}] * 6),
+        dict(label="wall_blocks_non_door", state=st(boarding_0=dict(pos=[4, 3]), exiting_0=dict(pos=[6, 5])),
+             steps=[{"boarding_0": U, "exiting_0": D}] * 3),
+        dict(label="side_walls", state=st(exiting_0=dict(pos=[2, 6]), exiting_1=dict(pos=[8, 5])),
+             steps=[{"exiting_0": Lf, "exiting_1": R}] * 2),
+        dict(label="forced_at_door_reward", state=st(boarding_0=dict(pos=[3, 4]), boarding_1=dict(pos=[7, 4])),
+             steps=[{"boarding_0": Wt, "boarding_1": Wt}, {"boarding_0": U, "boarding_1": D}]),
+        dict(label="arrive_exactly_at_max_steps", step_count=5,
+             state=st(exiting_0=dict(pos=[5, 1])), steps=[{"exiting_0": D}, {"exiting_0": D}, {}]),
+        dict(label="step_after_all_done", step_count=5, state=st(), steps=[{}, {"boarding_0": R}, {}]),
+        dict(label="action_for_terminated_agent",
+             state=st(exiting_0=dict(pos=[5, 0], active=False, terminated=True)),
+             steps=[{"exiting_0": U, "boarding_0": R}, {"exiting_0": U}]),
+        dict(label="inactive_agent_does_not_block",
+             state=st(exiting_0=dict(pos=[3, 0], active=False, terminated=True), exiting_1=dict(pos=[3, 1])),
+             steps=[{"exiting_1": D}, {"exiting_1": Wt}]),
+        dict(label="swap_blocked_and_chain_order_forward",
+             state=st(boarding_0=dict(pos=[2, 2]), boarding_1=dict(pos=[3, 2])),
+             steps=[{"boarding_0": R, "boarding_1": R}, {"boarding_0": R, "boarding_1": Lf}]),
+        dict(label="chain_order_reversed",
+             state=st(boarding_0=dict(pos=[2, 2]), boarding_1=dict(pos=[3, 2])),
+             steps=[{"boarding_1": R, "boarding_0": R}, {"boarding_1": Lf, "boarding_0": R}]),
+        dict(label="same_target_first_wins",
+             state=st(boarding_0=dict(pos=[2, 2]), boarding_1=dict(pos=[4, 2])),
+             steps=[{"boarding_0": R, "boarding_1": Lf}, {"boarding_1": Lf, "boarding_0": R}]),
+        dict(label="truncated_agent_still_blocks",
+             state=st(boarding_0=dict(pos=[2, 2], truncated=True), boarding_1=dict(pos=[3, 2])),
+             steps=[{"boarding_1": Lf}, {"boarding_0": R, "boarding_1": Lf}]),
+        dict(label="omitted_agents_do_not_move", state=st(), steps=[{"boarding_1": Lf}, {}]),
+        dict(label="out_of_bounds_moves", state=st(boarding_0=dict(pos=[0, 0]), boarding_1=dict(pos=[10, 0])),
+             steps=[{"boarding_0": Lf, "boarding_1": R}, {"boarding_0": D, "boarding_1": D}]),
+        dict(label="exiting_through_door_and_outside_reward", state=st(exiting_0=dict(pos=[5, 5])),
+             steps=[{"exiting_0": D}] * 4),
+    ]
+    return cfg, sc
+
+
+def main() -> int:
+    if not (REF / "src" / "collectivecrossing").is_dir():
+        print(f"reference not found at {REF}: nothing to do (fixtures are committed)")
+        return 0
+    import_reference()
+    replay_reference_goldens()
+
+    # G1 / G2: BASELINE config-1 geometry, random actions, identity and shuffled move order
+    run_random("g1_c1_random", cfg_c1(), seeds=range(0, 24), K=110)
+    run_random("g2_c1_shuffled_absent", cfg_c1(), seeds=range(100, 116), K=110, shuffle=True,
+               p_absent=0.15)
+    # G3: dense collisions, SimpleDistance
+    run_random("g3_c3_dense_simple_distance", cfg_c3(), seeds=range(200, 204), K=110)
+    run_random("g3_c3_dense_shuffled", cfg_c3(), seeds=range(210, 212), K=60, shuffle=True)
+    # G4: AllAtDestination, greedy actions; legal 25+25 and reference-illegal 32+32
+    run_greedy("g4_c5_all_at_dest_greedy_25_25", cfg_c5(25, 25, max_steps=60), seeds=[300, 301], K=64)
+    run_greedy("g4_c5_all_at_dest_greedy_32_32", cfg_c5(32, 32, max_steps=40), seeds=[310], K=44)
+    run_greedy("g4_small_all_at_dest_greedy", cfg_small(
+        terminated_config=dict(terminated_function="all_at_destination")), seeds=range(320, 328), K=56)
+    run_greedy("g4_c1_individual_greedy", cfg_c1(), seeds=range(330, 338), K=110)
+    # G5: edge probes on forced states, under several strategy combinations
+    ecfg, esc = edge_scenarios()
+    run_scenarios("g5_edges_default", ecfg, esc)
+    run_scenarios("g5_edges_all_at_dest_binary", dict(
+        ecfg, terminated_config=dict(terminated_function="all_at_destination"),
+        reward_config=dict(reward_function="binary", goal_reward=3.0, no_goal_reward=-0.25)), esc)
+    run_scenarios("g5_edges_constant_negative", dict(
+        ecfg, reward_config=dict(reward_function="constant_negative", step_penalty=-1.5)), esc)
+    run_scenarios("g5_edges_simple_distance_zero_factor", dict(
+        ecfg, reward_config=dict(reward_function="simple_distance", distance_penalty_factor=0.0)), esc)
+    # sealed door (door_right - door_left == 1): nobody can ever cross
+    run_greedy("g5_sealed_door_greedy", dict(
+        width=10, height=8, division_y=4, tram_door_left=4, tram_door_right=5, tram_length=8,
+        num_boarding_agents=2, num_exiting_agents=1, exiting_destination_area_y=1,
+        boarding_destination_area_y=7,
+        truncated_config=dict(truncated_function="max_steps", max_steps=30)), seeds=[340, 341], K=34)
+    # G7: shape matrix -- N=1, odd N, padded lane groups (N=5, 12, 50), other rewards
+    run_random("g7_n1_boarding_only", cfg_small(num_boarding_agents=1, num_exiting_agents=0), seeds=range(400, 404), K=56)
+    run_random("g7_n1_exiting_only", cfg_small(num_boarding_agents=0, num_exiting_agents=1), seeds=range(410, 414), K=56)
+    run_random("g7_n3_small", cfg_small(), seeds=range(420, 436), K=56)
+    run_random("g7_n5_odd", cfg_c1(num_boarding_agents=3, num_exiting_agents=2), seeds=range(440, 448), K=110)
+    run_random("g7_n12_constant_negative", cfg_c1(
+        num_boarding_agents=7, num_exiting_agents=5,
+        reward_config=dict(reward_function="constant_negative", step_penalty=-0.5)), seeds=range(450, 454), K=110)
+    run_random("g7_n50_padded_group", cfg_c5(25, 25, max_steps=40, terminated_config=dict(
+        terminated_function="individual_at_destination")), seeds=[460], K=44, shuffle=True)
+    run_random("g7_default_reward_big_factor", cfg_c1(reward_config=dict(
+        reward_function="default", boarding_destination_reward=-7.25, tram_door_reward=3.5,
+        tram_area_reward=0.3, distance_penalty_factor=9.7)), seeds=range(470, 474), K=110)
+    run_random("g7_live_agents_only_actions", cfg_c1(), seeds=range(480, 484), K=110, act_done=False)
+    # G8: auto-reset rollouts (pool = reference reset placements), incl. a 2-way shard view
+    run_rollout("g8_rollout_c1", cfg_c1(truncated_config=dict(truncated_function="max_steps", max_steps=25)),
+                E=12, K=90, P=64, seed0=5000)
+    run_rollout("g8_rollout_c1_shard1of2", cfg_c1(truncated_config=dict(truncated_function="max_steps", max_steps=25)),
+                E=6, K=90, P=64, seed0=5000, total_envs=12, env_offset=6)
+    run_rollout("g8_rollout_small_all_at_dest", cfg_small(
+        terminated_config=dict(terminated_function="all_at_destination"),
+        truncated_config=dict(truncated_function="max_steps", max_steps=12)), E=8, K=60, P=32, seed0=6000)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
