@@ -1,0 +1,254 @@
+"""Array-native batched environment: E independent CollectiveCrossing envs on one MI355X.
+
+Thin Python over the C-ABI of libccx (``include/ccx.h``).  torch is used for plumbing only --
+device buffers, the HIP stream, and (in :mod:`.sharding`) the RCCL process group; every compute
+call goes through ``ctypes`` into the HIP library.  Layouts are the library's: env-major SoA,
+``[E, N]`` per-agent arrays, observations ``[E, N, L]`` with ``L = 6 + 4N``.
+
+The reference has no batched API; the per-env semantics are those of
+``CollectiveCrossingEnv.reset/step`` (collectivecrossing.py:91-261).  The dict API of the
+reference is layered on top of this class in :mod:`.env`.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._lib import check, load
+from .configs import CollectiveCrossingConfig
+from .params import agent_ids, lower_config
+from .reset import build_reset_pool, seeded_positions
+
+
+@dataclass
+class StepResult:
+    """Device tensors of one step (views into buffers owned by the env, overwritten next step)."""
+
+    obs: torch.Tensor | None  # f32 [E, N, L]
+    reward: torch.Tensor      # f64 [E, N]
+    agent_flags: torch.Tensor  # u8 [E, N]  (_abi.AF_*)
+    env_flags: torch.Tensor   # u8 [E]     (_abi.EF_*)
+
+
+@dataclass
+class RolloutResult:
+    obs: torch.Tensor | None   # f32 [K, E, N, L]
+    reward: torch.Tensor | None  # f64 [K, E, N]
+    agent_flags: torch.Tensor | None  # u8 [K, E, N]
+    env_flags: torch.Tensor | None    # u8 [K, E]
+
+
+def _ptr(t: torch.Tensor | None) -> C.c_void_p:
+    return C.c_void_p(None if t is None else t.data_ptr())
+
+
+class BatchedCollectiveCrossing:
+    """E envs sharing one config, resident on one GPU for their whole life."""
+
+    def __init__(self, config: CollectiveCrossingConfig, num_envs: int, device: int | str | None = None,
+                 env_offset: int = 0, total_envs: int | None = None):
+        self._lib = load()
+        self.config = config
+        self.params = lower_config(config)
+        self.num_envs = int(num_envs)
+        self.num_agents = self.params.num_agents
+        self.obs_len = 6 + 4 * self.num_agents
+        self.agent_ids = agent_ids(config)
+        self.env_offset = int(env_offset)
+        self.total_envs = int(total_envs if total_envs is not None else num_envs)
+        if not torch.cuda.is_available():
+            raise RuntimeError("collectivecrossing_amd needs an MI355X: torch sees no GPU and libccx "
+                               "has no CPU path")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise ValueError(f"device must be a GPU, got {dev}")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self._stream = torch.cuda.current_stream(self.device)
+        handle = C.c_void_p()
+        check(self._lib.ccx_create(C.byref(self.params), self.num_envs, self.env_offset, self.total_envs,
+                                   self.device.index, C.c_void_p(self._stream.cuda_stream),
+                                   C.byref(handle)))
+        self._h = handle
+        self._pool: torch.Tensor | None = None
+        self._step_bufs: StepResult | None = None
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.ccx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _new(self, shape, dtype) -> torch.Tensor:
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _as_dev_u8(self, a, shape) -> torch.Tensor:
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=torch.uint8)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(a, np.uint8)).to(self.device)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t.contiguous()
+
+    # ------------------------------------------------------------------ state
+    def set_state(self, x=None, y=None, active=None, terminated=None, truncated=None,
+                  step_count=None, episode=None) -> None:
+        """Overwrite (parts of) the SoA state from host arrays (``ccx_set_state_host``)."""
+        E, N = self.num_envs, self.num_agents
+        keep = []
+
+        def conv(a, dt, shape):
+            if a is None:
+                return None
+            arr = np.ascontiguousarray(np.asarray(a, dt).reshape(shape))
+            keep.append(arr)
+            return arr.ctypes.data
+
+        st = _abi.CcxState(conv(x, np.int32, (E, N)), conv(y, np.int32, (E, N)),
+                           conv(active, np.uint8, (E, N)), conv(terminated, np.uint8, (E, N)),
+                           conv(truncated, np.uint8, (E, N)), conv(step_count, np.int32, (E,)),
+                           conv(episode, np.int32, (E,)))
+        check(self._lib.ccx_set_state_host(self._h, C.byref(st)))
+
+    def get_state(self) -> dict[str, np.ndarray]:
+        E, N = self.num_envs, self.num_agents
+        out = dict(x=np.empty((E, N), np.int32), y=np.empty((E, N), np.int32),
+                   active=np.empty((E, N), np.uint8), terminated=np.empty((E, N), np.uint8),
+                   truncated=np.empty((E, N), np.uint8), step_count=np.empty((E,), np.int32),
+                   episode=np.empty((E,), np.int32))
+        st = _abi.CcxState(*[out[k].ctypes.data for k in
+                             ("x", "y", "active", "terminated", "truncated", "step_count", "episode")])
+        check(self._lib.ccx_get_state_host(self._h, C.byref(st)))
+        return out
+
+    # ------------------------------------------------------------------ reset
+    def reset(self, seeds) -> torch.Tensor:
+        """``reset(seed=seeds[e])`` for every env (host placement, exact); returns obs [E,N,L]."""
+        seeds = np.asarray(seeds).reshape(-1)
+        if len(seeds) != self.num_envs:
+            raise ValueError(f"need {self.num_envs} seeds, got {len(seeds)}")
+        pos = seeded_positions(self.config, seeds)
+        E, N = self.num_envs, self.num_agents
+        self.set_state(x=pos[..., 0], y=pos[..., 1], active=np.ones((E, N), np.uint8),
+                       terminated=np.zeros((E, N), np.uint8), truncated=np.zeros((E, N), np.uint8),
+                       step_count=np.zeros(E, np.int32))
+        return self.observe()
+
+    def set_reset_pool(self, pool_xy) -> None:
+        """Install seeded placements ``u8 [P, N, 2]`` for ``reset_from_pool`` / auto-reset."""
+        if isinstance(pool_xy, torch.Tensor):
+            t = pool_xy.to(device=self.device, dtype=torch.uint8).contiguous()
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(pool_xy, np.uint8)).to(self.device)
+        if t.ndim != 3 or tuple(t.shape[1:]) != (self.num_agents, 2):
+            raise ValueError(f"pool must be [P, {self.num_agents}, 2], got {tuple(t.shape)}")
+        self._pool = t
+        check(self._lib.ccx_set_reset_pool(self._h, _ptr(t), t.shape[0]))
+
+    def make_reset_pool(self, seed0: int, size: int) -> None:
+        self.set_reset_pool(build_reset_pool(self.config, seed0, size))
+
+    def reset_from_pool(self, env_mask=None) -> None:
+        m = None if env_mask is None else self._as_dev_u8(env_mask, (self.num_envs,))
+        check(self._lib.ccx_reset_from_pool(self._h, _ptr(m)))
+
+    # ------------------------------------------------------------------ compute
+    def observe(self, out: torch.Tensor | None = None) -> torch.Tensor:
+        if out is None:
+            out = self._new((self.num_envs, self.num_agents, self.obs_len), torch.float32)
+        check(self._lib.ccx_observe(self._h, _ptr(out)))
+        return out
+
+    def step(self, actions, order=None, want_obs: bool = True) -> StepResult:
+        E, N = self.num_envs, self.num_agents
+        a = self._as_dev_u8(actions, (E, N))
+        o = None if order is None else self._as_dev_u8(order, (E, N))
+        if self._step_bufs is None:
+            self._step_bufs = StepResult(self._new((E, N, self.obs_len), torch.float32),
+                                         self._new((E, N), torch.float64),
+                                         self._new((E, N), torch.uint8), self._new((E,), torch.uint8))
+        b = self._step_bufs
+        so = _abi.CcxStepOut(_ptr(b.obs if want_obs else None).value, _ptr(b.reward).value,
+                             _ptr(b.agent_flags).value, _ptr(b.env_flags).value)
+        check(self._lib.ccx_step(self._h, _ptr(a), _ptr(o), C.byref(so)))
+        return StepResult(b.obs if want_obs else None, b.reward, b.agent_flags, b.env_flags)
+
+    def alloc_rollout(self, num_steps: int, want_obs: bool = True) -> RolloutResult:
+        K, E, N = num_steps, self.num_envs, self.num_agents
+        return RolloutResult(self._new((K, E, N, self.obs_len), torch.float32) if want_obs else None,
+                             self._new((K, E, N), torch.float64), self._new((K, E, N), torch.uint8),
+                             self._new((K, E), torch.uint8))
+
+    def rollout(self, actions, order=None, auto_reset: bool = False,
+                out: RolloutResult | None = None, want_obs: bool = True,
+                want_traj: bool = True) -> RolloutResult | None:
+        """K fused steps (``ccx_rollout``); ``actions`` u8 [K, E, N] on the device."""
+        K = int(actions.shape[0])
+        E, N = self.num_envs, self.num_agents
+        a = self._as_dev_u8(actions, (K, E, N))
+        o = None if order is None else self._as_dev_u8(order, (K, E, N))
+        if out is None and want_traj:
+            out = self.alloc_rollout(K, want_obs)
+        if out is not None:
+            ro = _abi.CcxRolloutOut(_ptr(out.obs).value, _ptr(out.reward).value,
+                                    _ptr(out.agent_flags).value, _ptr(out.env_flags).value)
+            check(self._lib.ccx_rollout(self._h, K, _ptr(a), _ptr(o), int(bool(auto_reset)), C.byref(ro)))
+        else:
+            check(self._lib.ccx_rollout(self._h, K, _ptr(a), _ptr(o), int(bool(auto_reset)), None))
+        return out
+
+    # ------------------------------------------------------------------ counters / timing / shape
+    def zero_counters(self) -> None:
+        check(self._lib.ccx_zero_counters(self._h))
+
+    def counters(self) -> dict[str, int]:
+        c = _abi.CcxCounters()
+        check(self._lib.ccx_read_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def counters_tensor(self) -> torch.Tensor:
+        """Zero-copy int64 view of the 6 device counters (for the RCCL all-reduce)."""
+        p = C.c_void_p()
+        check(self._lib.ccx_counters_device_ptr(self._h, C.byref(p)))
+        return _device_view_i64(p.value, len(_abi.COUNTER_FIELDS), self.device)
+
+    def last_launch_ms(self) -> float:
+        ms = C.c_float()
+        check(self._lib.ccx_last_launch_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def set_launch_shape(self, lanes_per_wave: int = 0, waves_per_block: int = 0) -> None:
+        check(self._lib.ccx_set_launch_shape(self._h, lanes_per_wave, waves_per_block))
+
+    def launch_shape(self) -> dict[str, int]:
+        v = [C.c_int32() for _ in range(4)]
+        check(self._lib.ccx_get_launch_shape(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("lanes_per_wave", "waves_per_block", "group_lanes", "num_blocks"),
+                        (int(x.value) for x in v)))
+
+    def synchronize(self) -> None:
+        check(self._lib.ccx_synchronize(self._h))
+
+
+class _CudaArrayView:
+    """Minimal ``__cuda_array_interface__`` carrier so torch can wrap library-owned memory."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False),
+                                         "version": 3, "strides": None}
+
+
+def _device_view_i64(ptr: int, n: int, device: torch.device) -> torch.Tensor:
+    return torch.as_tensor(_CudaArrayView(ptr, n), device=device)

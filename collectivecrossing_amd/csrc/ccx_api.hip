@@ -1,0 +1,439 @@
+// ccx_api.hip -- the C-ABI of libccx (include/ccx.h) on top of the gfx950 kernels.
+//
+// Host-side only: argument validation, device memory for the SoA state, launch-shape selection,
+// HIP-event timing.  No compute happens here and there is NO CPU fallback: every entry point that
+// steps envs launches a kernel or fails with a ccx_status.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/ccx.h"
+#include "ccx_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define CCX_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(CCX_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),      \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+int ceil_log2(int n) {
+    int g = 0;
+    while ((1 << g) < n) ++g;
+    return g;
+}
+
+}  // namespace
+
+struct ccx_handle {
+    ccx_params params{};
+    int32_t E = 0, N = 0;
+    int64_t env_offset = 0, total_envs = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ccx::KState st{};
+    unsigned long long* counters = nullptr;  // 6 x u64
+    const uint8_t* pool = nullptr;
+    int64_t pool_size = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    int lanes_per_wave = 0, waves_per_block = 0;  // user overrides (0 = default)
+    ccx::LaunchShape shape{};
+    ccx::KParams kp{};
+};
+
+namespace {
+
+// Default launch shape.  The per-wave instruction stream does not depend on how many lanes carry
+// agents, so for small batches fewer envs per wave (more waves) uses more of the 1024 SIMDs;
+// once every SIMD has a couple of waves, fuller waves are cheaper.
+void choose_shape(ccx_handle* h) {
+    const int glog = ceil_log2(h->N);
+    const int G = 1 << glog;
+    const int max_ew = 64 / G;
+    int ew;
+    if (h->lanes_per_wave > 0) {
+        ew = h->lanes_per_wave / G;
+    } else {
+        const int target_waves = 2048;
+        ew = max_ew;
+        while (ew > 1 && (h->E + ew - 1) / ew < target_waves) ew >>= 1;
+    }
+    if (ew < 1) ew = 1;
+    if (ew > max_ew) ew = max_ew;
+    const int waves = (h->E + ew - 1) / ew;
+    int wpb = h->waves_per_block > 0 ? h->waves_per_block : (waves > 4096 ? 4 : 1);
+    if (wpb > 4) wpb = 4;
+    ccx::LaunchShape& s = h->shape;
+    s.glog = glog;
+    s.envs_per_wave = ew;
+    s.waves_per_block = wpb;
+    s.num_blocks = (waves + wpb - 1) / wpb;
+    const int units = ew * h->N * (3 + 2 * h->N);
+    size_t lds = (size_t)wpb * 1312u + (size_t)(units + 2) * 2u;
+    s.lds_bytes = (lds + 15u) & ~(size_t)15u;
+
+    ccx::KParams& k = h->kp;
+    const ccx_params& p = h->params;
+    k.W = p.width; k.H = p.height; k.div = p.division_y;
+    k.tl = p.tram_left; k.tr = p.tram_right; k.dl = p.door_left; k.dr = p.door_right;
+    k.dc = (p.door_left + p.door_right) / 2;  // observations.py:70-71, rewards.py:81
+    k.Nb = p.num_boarding; k.N = h->N; k.bdy = p.boarding_dest_y; k.edy = p.exiting_dest_y;
+    k.reward_mode = p.reward_mode; k.term_mode = p.terminated_mode; k.max_steps = p.max_steps;
+    k.E = h->E; k.EW = ew; k.waves_per_block = wpb; k.units_per_wave = units; k._pad = 0;
+    k.r_dest = p.boarding_destination_reward; k.r_door = p.tram_door_reward;
+    k.r_area = p.tram_area_reward; k.r_f = p.distance_penalty_factor;
+    k.r_nogoal = p.no_goal_reward; k.r_pen = p.step_penalty;
+    k.env_offset = h->env_offset;
+    k.pool_size = h->pool_size;
+    k.pool_stride = h->pool_size > 0 ? (long long)(h->total_envs % h->pool_size) : 0;
+}
+
+int validate_params(const ccx_params* p) {
+    if (!p) return fail(CCX_EINVAL, "params is NULL");
+    const int n = p->num_boarding + p->num_exiting;
+    if (p->num_boarding < 0 || p->num_exiting < 0 || n < 1)
+        return fail(CCX_EINVAL, "need at least one agent (got %d boarding + %d exiting)",
+                    p->num_boarding, p->num_exiting);
+    if (n > 64)
+        return fail(CCX_EINVAL, "%d agents per env: libccx supports at most 64 (one wavefront "
+                    "lane per agent); the reference itself caps the total at 50 (configs.py:166)", n);
+    if (p->width < 1 || p->width > 100 || p->height < 1 || p->height > 100)
+        return fail(CCX_EINVAL, "grid %dx%d outside 1..100 (configs.py:39-40)", p->width, p->height);
+    if (p->division_y < 1 || p->division_y > 100) return fail(CCX_EINVAL, "division_y out of range");
+    if (p->reward_mode < 0 || p->reward_mode > 3) return fail(CCX_EINVAL, "unknown reward_mode %d", p->reward_mode);
+    if (p->terminated_mode < 0 || p->terminated_mode > 1)
+        return fail(CCX_EINVAL, "unknown terminated_mode %d", p->terminated_mode);
+    if (p->truncated_mode != 0) return fail(CCX_EINVAL, "unknown truncated_mode %d", p->truncated_mode);
+    if (p->max_steps < 1) return fail(CCX_EINVAL, "max_steps must be >= 1");
+    return CCX_OK;
+}
+
+int begin_timed(ccx_handle* h) {
+    CCX_HIP(hipEventRecord(h->ev_start, h->stream));
+    return CCX_OK;
+}
+int end_timed(ccx_handle* h) {
+    CCX_HIP(hipEventRecord(h->ev_stop, h->stream));
+    h->timed = true;
+    return CCX_OK;
+}
+
+int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* order, int auto_reset,
+                const ccx::KOut& out) {
+    if (out.obs && (reinterpret_cast<uintptr_t>(out.obs) & 15u))
+        return fail(CCX_EINVAL, "obs buffer must be 16-byte aligned");
+    if (out.reward && (reinterpret_cast<uintptr_t>(out.reward) & 7u))
+        return fail(CCX_EINVAL, "reward buffer must be 8-byte aligned");
+    CCX_HIP(hipSetDevice(h->device));
+    int rc = begin_timed(h);
+    if (rc) return rc;
+    hipError_t e = ccx::launch_rollout(h->shape, h->stream, h->kp, h->st, actions, order, K,
+                                       auto_reset, h->pool, out, h->counters);
+    if (e != hipSuccess) return fail(CCX_EHIP, "rollout kernel launch failed: %s", hipGetErrorString(e));
+    return end_timed(h);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ccx_abi_version(void) { return CCX_ABI_VERSION; }
+
+const char* ccx_build_info(void) {
+    static char buf[128];
+    snprintf(buf, sizeof(buf), "libccx 0.1.0 abi %d gfx950 hip %d.%d", CCX_ABI_VERSION,
+             HIP_VERSION_MAJOR, HIP_VERSION_MINOR);
+    return buf;
+}
+
+const char* ccx_last_error(void) { return g_err; }
+
+int32_t ccx_obs_len(int32_t num_agents) { return 2 + 4 + 4 * num_agents; }
+
+int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, int64_t total_envs,
+               int device, void* stream, ccx_handle** out) {
+    if (!out) return fail(CCX_EINVAL, "out is NULL");
+    *out = nullptr;
+    int rc = validate_params(params);
+    if (rc) return rc;
+    if (num_envs < 1) return fail(CCX_EINVAL, "num_envs must be >= 1 (got %d)", num_envs);
+    if (total_envs <= 0) total_envs = num_envs;
+    if (env_offset < 0 || env_offset + num_envs > total_envs)
+        return fail(CCX_EINVAL, "env_offset %lld + num_envs %d exceeds total_envs %lld",
+                    (long long)env_offset, num_envs, (long long)total_envs);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(CCX_ENODEVICE, "no HIP device visible: libccx has no CPU path");
+    if (device < 0 || device >= ndev) return fail(CCX_EINVAL, "device %d out of range (%d visible)", device, ndev);
+    hipDeviceProp_t prop;
+    CCX_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CCX_ENODEVICE, "device %d is %s; libccx carries gfx950 (MI355X) code only", device,
+                    prop.gcnArchName);
+    CCX_HIP(hipSetDevice(device));
+
+    ccx_handle* h = new (std::nothrow) ccx_handle();
+    if (!h) return fail(CCX_ENOMEM, "host allocation failed");
+    h->params = *params;
+    h->E = num_envs;
+    h->N = params->num_boarding + params->num_exiting;
+    h->env_offset = env_offset;
+    h->total_envs = total_envs;
+    h->device = device;
+    h->stream = reinterpret_cast<hipStream_t>(stream);
+    const size_t en = (size_t)h->E * h->N;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(p, bytes);
+    };
+    alloc((void**)&h->st.x, en * 4);
+    alloc((void**)&h->st.y, en * 4);
+    alloc((void**)&h->st.active, en);
+    alloc((void**)&h->st.terminated, en);
+    alloc((void**)&h->st.truncated, en);
+    alloc((void**)&h->st.step_count, (size_t)h->E * 4);
+    alloc((void**)&h->st.episode, (size_t)h->E * 4);
+    alloc((void**)&h->counters, 6 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_start);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_stop);
+    if (e == hipSuccess) e = hipMemsetAsync(h->st.x, 0, en * 4, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->st.y, 0, en * 4, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->st.active, 1, en, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->st.terminated, 0, en, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->st.truncated, 0, en, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->st.step_count, 0, (size_t)h->E * 4, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->st.episode, 0, (size_t)h->E * 4, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->counters, 0, 6 * sizeof(unsigned long long), h->stream);
+    if (e != hipSuccess) {
+        int code = (e == hipErrorOutOfMemory) ? CCX_ENOMEM : CCX_EHIP;
+        fail(code, "ccx_create: %s", hipGetErrorString(e));
+        ccx_destroy(h);
+        return code;
+    }
+    choose_shape(h);
+    *out = h;
+    return CCX_OK;
+}
+
+void ccx_destroy(ccx_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->st.x);
+    (void)hipFree(h->st.y);
+    (void)hipFree(h->st.active);
+    (void)hipFree(h->st.terminated);
+    (void)hipFree(h->st.truncated);
+    (void)hipFree(h->st.step_count);
+    (void)hipFree(h->st.episode);
+    (void)hipFree(h->counters);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    delete h;
+}
+
+int32_t ccx_num_envs(const ccx_handle* h) { return h ? h->E : 0; }
+int32_t ccx_num_agents(const ccx_handle* h) { return h ? h->N : 0; }
+
+int ccx_state_view(ccx_handle* h, ccx_state* out) {
+    if (!h || !out) return fail(CCX_EINVAL, "NULL argument");
+    out->x = h->st.x;
+    out->y = h->st.y;
+    out->active = h->st.active;
+    out->terminated = h->st.terminated;
+    out->truncated = h->st.truncated;
+    out->step_count = h->st.step_count;
+    out->episode = h->st.episode;
+    return CCX_OK;
+}
+
+int ccx_set_state_host(ccx_handle* h, const ccx_state* src) {
+    if (!h || !src) return fail(CCX_EINVAL, "NULL argument");
+    const size_t en = (size_t)h->E * h->N;
+    if (src->x)
+        for (size_t t = 0; t < en; ++t)
+            if (src->x[t] < 0 || src->x[t] > h->params.width)
+                return fail(CCX_EINVAL, "x[%zu] = %d outside 0..width=%d (collectivecrossing.py:515)", t,
+                            src->x[t], h->params.width);
+    if (src->y)
+        for (size_t t = 0; t < en; ++t)
+            if (src->y[t] < 0 || src->y[t] > h->params.height)
+                return fail(CCX_EINVAL, "y[%zu] = %d outside 0..height=%d (collectivecrossing.py:515)", t,
+                            src->y[t], h->params.height);
+    const uint8_t* flags[3] = {src->active, src->terminated, src->truncated};
+    for (const uint8_t* f : flags)
+        if (f)
+            for (size_t t = 0; t < en; ++t)
+                if (f[t] > 1) return fail(CCX_EINVAL, "flag value %u at %zu is not 0/1", f[t], t);
+    if (src->step_count)
+        for (int32_t e = 0; e < h->E; ++e)
+            if (src->step_count[e] < 0) return fail(CCX_EINVAL, "negative step_count");
+    if (src->episode)
+        for (int32_t e = 0; e < h->E; ++e)
+            if (src->episode[e] < 0) return fail(CCX_EINVAL, "negative episode");
+    CCX_HIP(hipSetDevice(h->device));
+    CCX_HIP(hipStreamSynchronize(h->stream));
+    if (src->x) CCX_HIP(hipMemcpy(h->st.x, src->x, en * 4, hipMemcpyHostToDevice));
+    if (src->y) CCX_HIP(hipMemcpy(h->st.y, src->y, en * 4, hipMemcpyHostToDevice));
+    if (src->active) CCX_HIP(hipMemcpy(h->st.active, src->active, en, hipMemcpyHostToDevice));
+    if (src->terminated) CCX_HIP(hipMemcpy(h->st.terminated, src->terminated, en, hipMemcpyHostToDevice));
+    if (src->truncated) CCX_HIP(hipMemcpy(h->st.truncated, src->truncated, en, hipMemcpyHostToDevice));
+    if (src->step_count)
+        CCX_HIP(hipMemcpy(h->st.step_count, src->step_count, (size_t)h->E * 4, hipMemcpyHostToDevice));
+    if (src->episode) CCX_HIP(hipMemcpy(h->st.episode, src->episode, (size_t)h->E * 4, hipMemcpyHostToDevice));
+    return CCX_OK;
+}
+
+int ccx_get_state_host(ccx_handle* h, ccx_state* dst) {
+    if (!h || !dst) return fail(CCX_EINVAL, "NULL argument");
+    const size_t en = (size_t)h->E * h->N;
+    CCX_HIP(hipSetDevice(h->device));
+    CCX_HIP(hipStreamSynchronize(h->stream));
+    if (dst->x) CCX_HIP(hipMemcpy(dst->x, h->st.x, en * 4, hipMemcpyDeviceToHost));
+    if (dst->y) CCX_HIP(hipMemcpy(dst->y, h->st.y, en * 4, hipMemcpyDeviceToHost));
+    if (dst->active) CCX_HIP(hipMemcpy(dst->active, h->st.active, en, hipMemcpyDeviceToHost));
+    if (dst->terminated) CCX_HIP(hipMemcpy(dst->terminated, h->st.terminated, en, hipMemcpyDeviceToHost));
+    if (dst->truncated) CCX_HIP(hipMemcpy(dst->truncated, h->st.truncated, en, hipMemcpyDeviceToHost));
+    if (dst->step_count)
+        CCX_HIP(hipMemcpy(dst->step_count, h->st.step_count, (size_t)h->E * 4, hipMemcpyDeviceToHost));
+    if (dst->episode) CCX_HIP(hipMemcpy(dst->episode, h->st.episode, (size_t)h->E * 4, hipMemcpyDeviceToHost));
+    return CCX_OK;
+}
+
+int ccx_set_reset_pool(ccx_handle* h, const uint8_t* pool_xy, int64_t pool_size) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if ((pool_xy == nullptr) != (pool_size == 0) || pool_size < 0 || pool_size >= (1ll << 31))
+        return fail(CCX_EINVAL, "bad reset pool (ptr %p, size %lld)", (const void*)pool_xy, (long long)pool_size);
+    if (reinterpret_cast<uintptr_t>(pool_xy) & 1u) return fail(CCX_EINVAL, "pool must be 2-byte aligned");
+    h->pool = pool_xy;
+    h->pool_size = pool_size;
+    choose_shape(h);
+    return CCX_OK;
+}
+
+int ccx_reset_from_pool(ccx_handle* h, const uint8_t* env_mask) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if (!h->pool || h->pool_size <= 0) return fail(CCX_EINVAL, "no reset pool set (ccx_set_reset_pool)");
+    CCX_HIP(hipSetDevice(h->device));
+    hipError_t e = ccx::launch_reset_from_pool(h->stream, h->kp, h->st, env_mask, h->pool);
+    if (e != hipSuccess) return fail(CCX_EHIP, "reset kernel launch failed: %s", hipGetErrorString(e));
+    return CCX_OK;
+}
+
+int ccx_observe(ccx_handle* h, float* obs) {
+    if (!h || !obs) return fail(CCX_EINVAL, "NULL argument");
+    if (reinterpret_cast<uintptr_t>(obs) & 15u) return fail(CCX_EINVAL, "obs buffer must be 16-byte aligned");
+    CCX_HIP(hipSetDevice(h->device));
+    hipError_t e = ccx::launch_observe(h->shape, h->stream, h->kp, h->st, obs);
+    if (e != hipSuccess) return fail(CCX_EHIP, "observe kernel launch failed: %s", hipGetErrorString(e));
+    return CCX_OK;
+}
+
+int ccx_step(ccx_handle* h, const uint8_t* actions, const uint8_t* order, const ccx_step_out* out) {
+    if (!h || !actions) return fail(CCX_EINVAL, "NULL argument");
+    ccx::KOut ko{};
+    if (out) {
+        ko.obs = out->obs;
+        ko.reward = out->reward;
+        ko.agent_flags = out->agent_flags;
+        ko.env_flags = out->env_flags;
+    }
+    return run_rollout(h, 1, actions, order, 0, ko);
+}
+
+int ccx_rollout(ccx_handle* h, int32_t num_steps, const uint8_t* actions, const uint8_t* order,
+                int32_t auto_reset, const ccx_rollout_out* out) {
+    if (!h || !actions) return fail(CCX_EINVAL, "NULL argument");
+    if (num_steps < 1) return fail(CCX_EINVAL, "num_steps must be >= 1");
+    if (auto_reset && (!h->pool || h->pool_size <= 0))
+        return fail(CCX_EINVAL, "auto_reset needs a reset pool (ccx_set_reset_pool)");
+    ccx::KOut ko{};
+    if (out) {
+        ko.obs = out->obs;
+        ko.reward = out->reward;
+        ko.agent_flags = out->agent_flags;
+        ko.env_flags = out->env_flags;
+    }
+    return run_rollout(h, num_steps, actions, order, auto_reset ? 1 : 0, ko);
+}
+
+int ccx_zero_counters(ccx_handle* h) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    CCX_HIP(hipSetDevice(h->device));
+    CCX_HIP(hipMemsetAsync(h->counters, 0, 6 * sizeof(unsigned long long), h->stream));
+    return CCX_OK;
+}
+
+int ccx_read_counters(ccx_handle* h, ccx_counters* out_host) {
+    if (!h || !out_host) return fail(CCX_EINVAL, "NULL argument");
+    static_assert(sizeof(ccx_counters) == 6 * sizeof(unsigned long long), "counter layout");
+    CCX_HIP(hipSetDevice(h->device));
+    CCX_HIP(hipStreamSynchronize(h->stream));
+    CCX_HIP(hipMemcpy(out_host, h->counters, sizeof(ccx_counters), hipMemcpyDeviceToHost));
+    return CCX_OK;
+}
+
+int ccx_counters_device_ptr(ccx_handle* h, uint64_t** out) {
+    if (!h || !out) return fail(CCX_EINVAL, "NULL argument");
+    *out = reinterpret_cast<uint64_t*>(h->counters);
+    return CCX_OK;
+}
+
+int ccx_last_launch_ms(ccx_handle* h, float* ms) {
+    if (!h || !ms) return fail(CCX_EINVAL, "NULL argument");
+    if (!h->timed) return fail(CCX_EINVAL, "no timed launch yet");
+    CCX_HIP(hipSetDevice(h->device));
+    CCX_HIP(hipEventSynchronize(h->ev_stop));
+    CCX_HIP(hipEventElapsedTime(ms, h->ev_start, h->ev_stop));
+    return CCX_OK;
+}
+
+int ccx_set_launch_shape(ccx_handle* h, int32_t lanes_per_wave, int32_t waves_per_block) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    const int G = 1 << ceil_log2(h->N);
+    if (lanes_per_wave != 0 && (lanes_per_wave < G || lanes_per_wave > 64 || lanes_per_wave % G))
+        return fail(CCX_EINVAL, "lanes_per_wave %d must be a multiple of the env lane group %d and <= 64",
+                    lanes_per_wave, G);
+    if (waves_per_block < 0 || waves_per_block > 4) return fail(CCX_EINVAL, "waves_per_block must be 0..4");
+    h->lanes_per_wave = lanes_per_wave;
+    h->waves_per_block = waves_per_block;
+    choose_shape(h);
+    return CCX_OK;
+}
+
+int ccx_get_launch_shape(ccx_handle* h, int32_t* lanes_per_wave, int32_t* waves_per_block,
+                         int32_t* group_lanes, int32_t* num_blocks) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if (lanes_per_wave) *lanes_per_wave = h->shape.envs_per_wave << h->shape.glog;
+    if (waves_per_block) *waves_per_block = h->shape.waves_per_block;
+    if (group_lanes) *group_lanes = 1 << h->shape.glog;
+    if (num_blocks) *num_blocks = h->shape.num_blocks;
+    return CCX_OK;
+}
+
+int ccx_synchronize(ccx_handle* h) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    CCX_HIP(hipSetDevice(h->device));
+    CCX_HIP(hipStreamSynchronize(h->stream));
+    return CCX_OK;
+}
+
+}  // extern "C"

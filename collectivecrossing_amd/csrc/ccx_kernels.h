@@ -1,0 +1,64 @@
+// ccx_kernels.h -- types shared by the kernel translation unit and the C-ABI layer (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ccx {
+
+enum : uint32_t { CCX_K_ABSENT = 255u };
+enum : int { CCX_K_REWARD_DEFAULT = 0, CCX_K_REWARD_SIMPLE_DISTANCE = 1, CCX_K_REWARD_BINARY = 2,
+             CCX_K_REWARD_CONSTANT_NEGATIVE = 3 };
+enum : int { CCX_K_TERM_INDIVIDUAL = 0, CCX_K_TERM_ALL = 1 };
+enum : uint32_t { CCX_K_EF_ALL_TERM = 1u, CCX_K_EF_ALL_TRUNC = 2u, CCX_K_EF_RESET = 4u };
+
+// kernel parameters (passed by value; lives in SGPRs / the kernarg segment)
+struct KParams {
+    int W, H, div, tl, tr, dl, dr, dc;   // grid + absolute tram/door columns, door centre
+    int Nb, N, bdy, edy;                 // boarding count, agents per env, destination rows
+    int reward_mode, term_mode, max_steps;
+    int E;                               // envs of this handle
+    int EW;                              // envs carried by one wavefront
+    int waves_per_block;
+    int units_per_wave;                  // EW * N * (3 + 2N) float2 units of observation per wave
+    int _pad;
+    double r_dest, r_door, r_area, r_f, r_nogoal, r_pen;
+    long long env_offset;                // global index of env 0 (sharding)
+    long long pool_size;                 // reset-pool entries (0 = none)
+    long long pool_stride;               // total_envs mod pool_size
+};
+
+struct KState {
+    int32_t* x;
+    int32_t* y;
+    uint8_t* active;
+    uint8_t* terminated;
+    uint8_t* truncated;
+    int32_t* step_count;
+    int32_t* episode;
+};
+
+struct KOut {
+    float* obs;
+    double* reward;
+    uint8_t* agent_flags;
+    uint8_t* env_flags;
+};
+
+struct LaunchShape {
+    int glog;             // log2 of the per-env lane group
+    int envs_per_wave;    // EW
+    int waves_per_block;
+    int num_blocks;
+    size_t lds_bytes;
+};
+
+hipError_t launch_rollout(const LaunchShape& ls, hipStream_t stream, const KParams& p,
+                          const KState& st, const uint8_t* actions, const uint8_t* order, int K,
+                          int auto_reset, const uint8_t* pool, const KOut& out,
+                          unsigned long long* counters);
+hipError_t launch_observe(const LaunchShape& ls, hipStream_t stream, const KParams& p,
+                          const KState& st, float* obs);
+hipError_t launch_reset_from_pool(hipStream_t stream, const KParams& p, const KState& st,
+                                  const uint8_t* env_mask, const uint8_t* pool);
+
+}  // namespace ccx

@@ -1,0 +1,245 @@
+"""GPU parity: libccx (HIP, through the C-ABI) vs the reference-recorded goldens and the CPU oracle.
+
+Bit-exact everywhere: positions, flags, observations (u32 bit patterns), rewards (f64 bit
+patterns, including the sign of zero).
+"""
+
+import numpy as np
+import pytest
+from _fixtures import ROLLOUT_NPZ, STEP_NPZ, Golden, assert_step_matches
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ccx():
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from collectivecrossing_amd.batched import BatchedCollectiveCrossing
+
+    return BatchedCollectiveCrossing
+
+
+def _np(t):
+    return None if t is None else t.cpu().numpy()
+
+
+def _check_rollout_vs_golden(g, res, state, counters=None):
+    obs, rew, af, ef = _np(res.obs), _np(res.reward), _np(res.agent_flags), _np(res.env_flags)
+    np.testing.assert_array_equal(af, g["agent_flags"], err_msg=f"{g.name} agent_flags")
+    np.testing.assert_array_equal(ef, g["env_flags"], err_msg=f"{g.name} env_flags")
+    np.testing.assert_array_equal(obs.view(np.uint32), g["obs"].view(np.uint32), err_msg=f"{g.name} obs")
+    live = (g["agent_flags"] & 4) != 0
+    np.testing.assert_array_equal(np.where(live, rew, 0).view(np.uint64),
+                                  np.where(live, g["reward"], 0).view(np.uint64), err_msg=f"{g.name} reward")
+    for k in ("x", "y", "active", "terminated", "truncated"):
+        np.testing.assert_array_equal(state[k], g[k][-1], err_msg=f"{g.name} final {k}")
+
+
+@pytest.mark.parametrize("name", STEP_NPZ)
+def test_step_by_step_matches_reference_vectors(ccx, name):
+    """ccx_step, one launch per step, against every reference-recorded step."""
+    g = Golden(name)
+    env = ccx(g.config, g.E)
+    env.set_state(**g.init_state())
+    for s in range(g.K):
+        r = env.step(g["actions"][s], g["order"][s])
+        assert_step_matches(g, s, _np(r.obs), _np(r.reward), _np(r.agent_flags), _np(r.env_flags),
+                            env.get_state())
+    env.close()
+
+
+@pytest.mark.parametrize("name", STEP_NPZ)
+def test_fused_rollout_matches_reference_vectors(ccx, name):
+    """ccx_rollout (state in registers for K steps) against the same vectors."""
+    g = Golden(name)
+    env = ccx(g.config, g.E)
+    env.set_state(**g.init_state())
+    res = env.rollout(g["actions"], g["order"])
+    _check_rollout_vs_golden(g, res, env.get_state())
+    c = env.counters()
+    assert c["env_steps"] == g.K * g.E and c["agent_steps"] == g.K * g.E * g.N
+    assert c["live_agent_steps"] == int(((g["agent_flags"] & 4) != 0).sum())
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["g1_c1_random", "g2_c1_shuffled_absent", "g3_c3_dense_shuffled",
+                                  "g7_n3_small", "g7_n5_odd", "g7_n12_constant_negative"])
+@pytest.mark.parametrize("shape", [(0, 1), (0, 4), (64, 2), (-1, 3)])
+def test_launch_shapes_do_not_change_results(ccx, name, shape):
+    """Every lanes-per-wave / waves-per-block choice gives identical bits."""
+    g = Golden(name)
+    env = ccx(g.config, g.E)
+    lanes, wpb = shape
+    group = env.launch_shape()["group_lanes"]
+    if lanes == -1:
+        lanes = group            # one env per wavefront
+    elif lanes == 64:
+        lanes = (64 // group) * group
+    env.set_launch_shape(lanes, wpb)
+    env.set_state(**g.init_state())
+    res = env.rollout(g["actions"], g["order"])
+    _check_rollout_vs_golden(g, res, env.get_state())
+    env.close()
+
+
+@pytest.mark.parametrize("name", ROLLOUT_NPZ)
+def test_autoreset_rollout_matches_reference(ccx, name):
+    g = Golden(name)
+    env = ccx(g.config, g.E, env_offset=int(g["env_offset"]), total_envs=int(g["total_envs"]))
+    env.set_reset_pool(g["pool_xy"])
+    env.reset_from_pool()
+    st = env.get_state()
+    np.testing.assert_array_equal(st["x"], g["init_x"])
+    np.testing.assert_array_equal(st["y"], g["init_y"])
+    res = env.rollout(g["actions"], None, auto_reset=True)
+    np.testing.assert_array_equal(_np(res.env_flags), g["env_flags"])
+    np.testing.assert_array_equal(_np(res.agent_flags), g["agent_flags"])
+    np.testing.assert_array_equal(_np(res.obs).view(np.uint32), g["obs"].view(np.uint32))
+    live = (g["agent_flags"] & 4) != 0
+    np.testing.assert_array_equal(np.where(live, _np(res.reward), 0).view(np.uint64),
+                                  np.where(live, g["reward"], 0).view(np.uint64))
+    st = env.get_state()
+    np.testing.assert_array_equal(st["episode"], g["final_episode"])
+    assert env.counters()["episodes"] == int(g["final_episode"].sum())
+    # split the same rollout into two launches: state + episode cursor survive the kernel boundary
+    env2 = ccx(g.config, g.E, env_offset=int(g["env_offset"]), total_envs=int(g["total_envs"]))
+    env2.set_reset_pool(g["pool_xy"])
+    env2.reset_from_pool()
+    h = g.K // 3
+    r1 = env2.rollout(g["actions"][:h], None, auto_reset=True)
+    r2 = env2.rollout(g["actions"][h:], None, auto_reset=True)
+    np.testing.assert_array_equal(np.concatenate([_np(r1.env_flags), _np(r2.env_flags)]), g["env_flags"])
+    np.testing.assert_array_equal(np.concatenate([_np(r1.obs), _np(r2.obs)]).view(np.uint32),
+                                  g["obs"].view(np.uint32))
+    env.close()
+    env2.close()
+
+
+def test_seeded_reset_and_observe_match_reference(ccx):
+    """reset(seed) placement + the observation reset() returns (collectivecrossing.py:153-159)."""
+    for name in ("g1_c1_random", "g7_n3_small", "g3_c3_dense_simple_distance"):
+        g = Golden(name)
+        env = ccx(g.config, g.E)
+        obs = _np(env.reset(g["seeds"]))
+        st = env.get_state()
+        np.testing.assert_array_equal(st["x"], g["init_x"])
+        np.testing.assert_array_equal(st["y"], g["init_y"])
+        np.testing.assert_array_equal(obs[:, :, 0], g["init_x"].astype(np.float32))
+        np.testing.assert_array_equal(obs[:, :, 1], g["init_y"].astype(np.float32))
+        env.close()
+
+
+# ---- against the oracle at sizes the goldens do not reach -------------------------------------
+def _random_case(oracle, ccx, cfg_name, E, K, seed, shuffle, auto_reset, shape=None, p_absent=0.0):
+    from collectivecrossing_amd.reset import build_reset_pool, seeded_positions
+
+    g = Golden(cfg_name)
+    rng = np.random.default_rng(seed)
+    N = g.N
+    actions = rng.integers(0, 5, size=(K, E, N), dtype=np.uint8)
+    if p_absent:
+        actions[rng.random((K, E, N)) < p_absent] = 255
+    order = None
+    if shuffle:
+        order = np.argsort(rng.random((K, E, N)), axis=-1).astype(np.uint8)
+    ob = oracle.OracleBatch(g.params, E)
+    env = ccx(g.config, E)
+    if shape:
+        env.set_launch_shape(*shape)
+    if auto_reset:
+        pool = build_reset_pool(g.config, 7000 + seed, 257)
+        ob.set_reset_pool(pool)
+        env.set_reset_pool(pool)
+        ob.reset_from_pool()
+        env.reset_from_pool()
+    else:
+        pos = seeded_positions(g.config, range(seed, seed + E))
+        ob.set_state(x=pos[..., 0], y=pos[..., 1])
+        env.set_state(x=pos[..., 0], y=pos[..., 1])
+    o_obs, o_rew, o_af, o_ef = ob.rollout(actions, order, auto_reset=auto_reset)
+    res = env.rollout(actions, order, auto_reset=auto_reset)
+    np.testing.assert_array_equal(_np(res.agent_flags), o_af)
+    np.testing.assert_array_equal(_np(res.env_flags), o_ef)
+    np.testing.assert_array_equal(_np(res.obs).view(np.uint32), o_obs.view(np.uint32))
+    np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64))
+    st = env.get_state()
+    for k in ("x", "y", "active", "terminated", "truncated", "step_count", "episode"):
+        np.testing.assert_array_equal(st[k], getattr(ob, k), err_msg=k)
+    c = env.counters()
+    assert c == ob.counters.as_dict()
+    env.close()
+    return c
+
+
+@pytest.mark.parametrize("cfg_name,E,K", [
+    ("g1_c1_random", 1000, 130), ("g1_c1_random", 4096, 40),
+    ("g3_c3_dense_simple_distance", 300, 120), ("g4_c5_all_at_dest_greedy_25_25", 70, 80),
+    ("g4_c5_all_at_dest_greedy_32_32", 40, 60), ("g7_n5_odd", 333, 120), ("g7_n1_boarding_only", 200, 60)])
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_rollout_equals_oracle(oracle, ccx, cfg_name, E, K, shuffle):
+    _random_case(oracle, ccx, cfg_name, E, K, seed=11, shuffle=shuffle, auto_reset=False, p_absent=0.05)
+
+
+@pytest.mark.parametrize("cfg_name,E,K", [("g8_rollout_c1", 777, 160), ("g8_rollout_small_all_at_dest", 501, 90),
+                                          ("g7_n5_odd", 129, 260)])
+def test_autoreset_rollout_equals_oracle(oracle, ccx, cfg_name, E, K):
+    c = _random_case(oracle, ccx, cfg_name, E, K, seed=5, shuffle=False, auto_reset=True)
+    assert c["episodes"] > 0
+
+
+def test_full_size_c2_properties(ccx):
+    """BASELINE config 2 at full size (4096 x 8): size-independent properties of a long
+    auto-reset rollout -- no two active agents ever share a cell, nobody stands in a wall,
+    step counters stay below max_steps, the counters add up."""
+    import torch
+
+    from collectivecrossing_amd.reset import build_reset_pool
+
+    g = Golden("g1_c1_random")
+    E, K, N = 4096, 400, 8
+    env = ccx(g.config, E)
+    env.set_reset_pool(build_reset_pool(g.config, 0, 1024))
+    env.reset_from_pool()
+    actions = torch.randint(0, 5, (K, E, N), dtype=torch.uint8, device=env.device,
+                            generator=torch.Generator(device=env.device).manual_seed(3))
+    res = env.rollout(actions, auto_reset=True)
+    obs = res.obs  # [K,E,N,L]
+    x, y = obs[..., 0].long(), obs[..., 1].long()
+    af = res.agent_flags.long()
+    active = (af & 0x40) != 0
+    p = g.params
+    assert bool(((x >= 0) & (x <= p.width) & (y >= 0) & (y <= p.height)).all())
+    on_wall_row = (y == p.division_y) & ~((x > p.door_left) & (x < p.door_right))
+    in_tram_rows = (y >= p.division_y) & ~((x > p.tram_left) & (x < p.tram_right))
+    assert not bool((on_wall_row | in_tram_rows).any())
+    key = torch.where(active, y * 128 + x, -1 - torch.arange(N, device=env.device).expand_as(x))
+    srt = key.sort(dim=-1).values
+    assert not bool((srt[..., 1:] == srt[..., :-1]).any()), "two active agents share a cell"
+    # every observer row agrees with the others about everybody's position
+    slots = obs[..., 6:].reshape(K, E, N, N, 4)
+    j = torch.arange(N, device=env.device)
+    others = slots[..., 0][:, :, (j + 1) % N, j]  # x of agent j as seen by observer j+1
+    assert bool((others == obs[..., 0]).all())
+    c = env.counters()
+    assert c["env_steps"] == K * E and c["agent_steps"] == K * E * N
+    assert c["episodes"] == int(((res.env_flags & 4) != 0).sum())
+    assert c["live_agent_steps"] == int(((af & 4) != 0).sum())
+    st = env.get_state()
+    assert (st["step_count"] < p.max_steps).all() and (st["step_count"] >= 0).all()
+    env.close()
+
+
+def test_errors_are_loud(ccx):
+    from collectivecrossing_amd._lib import CcxError
+
+    g = Golden("g7_n3_small")
+    env = ccx(g.config, 4)
+    with pytest.raises(CcxError, match="outside 0..width"):
+        env.set_state(x=np.full((4, 3), 99, np.int32))
+    with pytest.raises(CcxError, match="reset pool"):
+        env.rollout(np.zeros((2, 4, 3), np.uint8), auto_reset=True)
+    with pytest.raises(ValueError):
+        env.step(np.zeros((4, 2), np.uint8))
+    env.close()
