@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Throughput bench of the batched CollectiveCrossing step on MI355X (driver contract).
+
+Workload (BASELINE.json configs[1], SURVEY 8d "C2"): per GPU 4096 envs x 8 agents (5 boarding +
+3 exiting) on the 12x8 grid, DefaultReward + DefaultObservation, IndividualAtDestination,
+MaxSteps=100, uniform random actions read from a device tensor, auto-reset from a pool of
+reference-exact seeded placements.  A bench "step" = ONE env-step of every env of the batch, i.e.
+one pass of the hot path over the batch; steps are executed `--chunk` at a time by the fused
+``ccx_rollout`` kernel, which writes the full per-step outputs (observations f32 [E,N,L], rewards
+f64, flag bytes) of every step to a trajectory buffer in HBM.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  `value` = env-steps/s over ALL ranks with inputs resident in HBM,
+timed between barrier + synchronize pairs, max over ranks.  Weak scaling: every rank owns 4096
+envs of a global batch of N*4096; envs are independent, the only collective is the 48-byte
+all-reduce of the counters after the timed window.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def c2_config(max_steps: int = 100):
+    from collectivecrossing_amd.configs import CollectiveCrossingConfig, MaxStepsTruncatedConfig
+    return CollectiveCrossingConfig(
+        width=12, height=8, division_y=4, tram_door_left=5, tram_door_right=7, tram_length=9,
+        num_boarding_agents=5, num_exiting_agents=3, exiting_destination_area_y=0,
+        boarding_destination_area_y=8, truncated_config=MaxStepsTruncatedConfig(max_steps=max_steps))
+
+
+def rollout_bytes_per_agent_step(n_agents: int) -> int:
+    """Bytes one fused rollout launch MUST move per agent-step (state stays in registers):
+    observation row 4*(6+4N) + action 1 + reward f64 8 + agent flag byte 1 (+ 1/N env flag byte,
+    ignored).  SURVEY 8d's contract figure 16N+54 additionally counts a state read+write per step
+    (22 B) that the fused kernel does not do; both are reported."""
+    return 4 * (6 + 4 * n_agents) + 1 + 8 + 1
+
+
+def cpu_baseline(config, n_agents: int, seconds_target: float = 12.0) -> dict:
+    """The CPU oracle (a C port of the reference's sequential algorithm) on the host cores, same
+    workload (full trajectory outputs), bounded sample."""
+    from collectivecrossing_amd.params import lower_config
+    from collectivecrossing_amd.reset import build_reset_pool
+    from oracle import oracle as ref  # cpu_baseline leg only
+
+    params = lower_config(config)
+    pool = build_reset_pool(config, 0, 128)
+    cores = min(os.cpu_count() or 1, 16)
+    E_t, K = 64, 500  # per thread: 64 envs x 500 steps, trajectory 39 MB
+
+    def make(seed):
+        b = ref.OracleBatch(params, E_t)
+        b.set_reset_pool(pool)
+        b.reset_from_pool()
+        acts = np.random.default_rng(seed).integers(0, 5, size=(K, E_t, n_agents), dtype=np.uint8)
+        return b, acts
+
+    # single core
+    b, acts = make(0)
+    b.rollout(acts[:50], auto_reset=True)  # warm-up
+    t0 = time.perf_counter()
+    reps1 = 0
+    while time.perf_counter() - t0 < seconds_target * 0.4:
+        b.rollout(acts, auto_reset=True)
+        reps1 += 1
+    dt1 = time.perf_counter() - t0
+    single = reps1 * E_t * K / dt1
+    # all cores: one thread per core, each on its own envs (ctypes releases the GIL)
+    workers = [make(100 + i) for i in range(cores)]
+    reps = max(1, int(reps1 * 1.2))
+
+    def run(w):
+        for _ in range(reps):
+            w[0].rollout(w[1], auto_reset=True)
+
+    threads = [threading.Thread(target=run, args=(w,)) for w in workers]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dtm = time.perf_counter() - t0
+    multi = cores * reps * E_t * K / dtm
+    return {"value": multi, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "single_core_value": single,
+            "sample": (f"oracle/ccx_oracle.c ccxo_rollout, same config/outputs (full trajectory), "
+                       f"{cores} threads x {reps} x ({E_t} envs x {K} steps) in {dtm:.1f}s; "
+                       f"1 thread: {reps1} x ({E_t} x {K}) in {dt1:.1f}s"),
+            "reference_python_note": ("the Python reference itself steps ~2.4e3 env-steps/s on one "
+                                      "core of the build container (SURVEY 6 probe); it cannot "
+                                      "travel to the GPU box")}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--chunk", type=int, default=250, help="env-steps fused per kernel launch")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per wave carrying agents (0=auto)")
+    ap.add_argument("--wpb", type=int, default=0, help="waves per workgroup (0=auto)")
+    ap.add_argument("--pool", type=int, default=4096, help="reset-pool entries (seeds 0..pool-1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip the observation output")
+    args = ap.parse_args()
+
+    from collectivecrossing_amd import sharding
+    from collectivecrossing_amd.batched import BatchedCollectiveCrossing
+    from collectivecrossing_amd.reset import build_reset_pool
+
+    rank, world, local = sharding.init_from_env()
+    if world != args.gpus:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: start N>1 with "
+              "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    config = c2_config()
+    E = args.envs_per_gpu
+    total = E * world
+    env = BatchedCollectiveCrossing(config, E, device=dev, env_offset=rank * E, total_envs=total)
+    N, L = env.num_agents, env.obs_len
+    if args.lanes or args.wpb:
+        env.set_launch_shape(args.lanes, args.wpb)
+    env.set_reset_pool(build_reset_pool(config, 0, args.pool))
+    env.reset_from_pool()
+
+    chunk = max(1, min(args.chunk, args.steps))
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    n_act = max(args.steps, args.warmup, 1)
+    actions = torch.randint(0, 5, (n_act, E, N), dtype=torch.uint8, device=dev, generator=gen)
+    traj = env.alloc_rollout(chunk, want_obs=not args.no_obs)
+
+    def run(nsteps, events=None):
+        done = 0
+        while done < nsteps:
+            k = min(chunk, nsteps - done)
+            view = type(traj)(None if traj.obs is None else traj.obs[:k], traj.reward[:k],
+                              traj.agent_flags[:k], traj.env_flags[:k])
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            env.rollout(actions[done:done + k], auto_reset=True, out=view)
+            if events is not None:
+                e1.record()
+                events.append((e0, e1, k))
+            done += k
+
+    run(args.warmup)
+    env.zero_counters()
+    torch.cuda.synchronize(dev)
+    sharding.barrier()
+    torch.cuda.synchronize(dev)
+    events: list = []
+    t0 = time.perf_counter()
+    run(args.steps, events)
+    torch.cuda.synchronize(dev)
+    sharding.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = sharding.allreduce_max(elapsed)
+    counters = sharding.allreduce_counters(env.counters())   # the one RCCL reduction (48 B)
+
+    # kernel time from HIP events recorded on the launch stream, per launch
+    full = [(a.elapsed_time(b), k) for a, b, k in events if k == chunk]
+    kern_ms = float(np.mean([ms for ms, _ in full])) if full else float("nan")
+    bytes_unit = rollout_bytes_per_agent_step(N) - (4 * L if args.no_obs else 0)
+    launch_bytes = bytes_unit * chunk * E * N
+    achieved = launch_bytes / (kern_ms * 1e-3) / 1e9 if full else float("nan")
+    survey_unit = 16 * N + 54 + 4   # SURVEY 8d contract figure, f64 rewards
+    traffic = None
+    tf = ROOT / "profiles" / "r01_traffic.json"
+    if tf.exists():
+        try:
+            t = json.loads(tf.read_text())
+            if t.get("envs") == E and t.get("chunk") == chunk and t.get("agents") == N:
+                traffic = t.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        assert counters["env_steps"] == args.steps * total, counters
+        env_sps = args.steps * total / elapsed
+        line = {
+            "metric": "env-steps/sec, random-action rollout, 4096 envs x 8 agents per GPU",
+            "value": env_sps, "unit": "env-steps/s", "agent_steps_per_sec": env_sps * N,
+            "live_agent_steps_per_sec": counters["live_agent_steps"] / elapsed,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32 state / f32 obs / f64 reward",
+            "data": "synthetic",
+            "config": {"workload": "C2: 4096 envs x (5 boarding + 3 exiting) per GPU, 12x8 grid, "
+                                   "DefaultReward + DefaultObservation, individual_at_destination, "
+                                   "max_steps=100, uniform random actions, auto-reset from "
+                                   f"{args.pool} reference-exact seeded placements",
+                       "envs_per_gpu": E, "global_envs": total, "agents": N, "obs_len": L,
+                       "steps_per_launch": chunk, "launch_shape": env.launch_shape(),
+                       "outputs": "full trajectory" + (" (no obs)" if args.no_obs else "")},
+            "counters": counters,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "ccx::rollout_kernel<3,true>", "kernel_ms_per_launch": kern_ms,
+                         "bytes_per_agent_step": bytes_unit, "bytes_per_launch": launch_bytes,
+                         "achieved_survey_8d_GBs": (survey_unit * chunk * E * N / (kern_ms * 1e-3) / 1e9
+                                                    if full else None),
+                         "survey_8d_bytes_per_agent_step": survey_unit},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(config, N)
+        elif world > 1:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    env.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -49,7 +49,7 @@ struct ccx_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     ccx::KState st{};
-    unsigned long long* counters = nullptr;  // 6 x u64
+    unsigned long long* counters = nullptr;  // 6 x u64 (+ 10 spare words used by diagnostic builds)
     const uint8_t* pool = nullptr;
     int64_t pool_size = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -211,7 +211,7 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     alloc((void**)&h->st.truncated, en);
     alloc((void**)&h->st.step_count, (size_t)h->E * 4);
     alloc((void**)&h->st.episode, (size_t)h->E * 4);
-    alloc((void**)&h->counters, 6 * sizeof(unsigned long long));
+    alloc((void**)&h->counters, 16 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipEventCreate(&h->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_stop);
     if (e == hipSuccess) e = hipMemsetAsync(h->st.x, 0, en * 4, h->stream);
@@ -221,7 +221,7 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     if (e == hipSuccess) e = hipMemsetAsync(h->st.truncated, 0, en, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->st.step_count, 0, (size_t)h->E * 4, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->st.episode, 0, (size_t)h->E * 4, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->counters, 0, 6 * sizeof(unsigned long long), h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->counters, 0, 16 * sizeof(unsigned long long), h->stream);
     if (e != hipSuccess) {
         int code = (e == hipErrorOutOfMemory) ? CCX_ENOMEM : CCX_EHIP;
         fail(code, "ccx_create: %s", hipGetErrorString(e));
@@ -378,7 +378,7 @@ int ccx_rollout(ccx_handle* h, int32_t num_steps, const uint8_t* actions, const 
 int ccx_zero_counters(ccx_handle* h) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");
     CCX_HIP(hipSetDevice(h->device));
-    CCX_HIP(hipMemsetAsync(h->counters, 0, 6 * sizeof(unsigned long long), h->stream));
+    CCX_HIP(hipMemsetAsync(h->counters, 0, 16 * sizeof(unsigned long long), h->stream));
     return CCX_OK;
 }
 

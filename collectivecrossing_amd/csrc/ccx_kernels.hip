@@ -156,6 +156,41 @@ __device__ __forceinline__ void emit_obs(const WaveLds* wl, const uint16_t* tabl
 // ---------------------------------------------------------------------------------------------
 // the fused rollout / step kernel
 // ---------------------------------------------------------------------------------------------
+
+// Keep a wave-uniform value in VGPRs on purpose: the step loop needs ~60 scalars (geometry,
+// pointers, reward constants) next to the ballot masks, which overflows the 102 SGPRs and makes
+// hipcc spill SGPRs through v_writelane/v_readlane inside the loop.  VGPRs are plentiful here
+// (one or two waves per SIMD), so the loop-invariant values that are only used by vector
+// instructions anyway are pinned there.
+template <typename T> __device__ __forceinline__ T in_vgpr(T v) {
+    if constexpr (sizeof(T) == 8) {
+        unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+        asm volatile("" : "+v"(u));
+        return __builtin_bit_cast(T, u);
+    } else {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
+}
+
+// Diagnostic build only (-DCCX_STAMPS): s_memtime stamps around the segments of one step; wave 0
+// adds its per-segment cycle sums to counters[8..15].  Never compiled into libccx.so.
+#ifdef CCX_STAMPS
+#define CCX_STAMP(slot)                                                                     \
+    do {                                                                                    \
+        unsigned long long t_;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        stamp_sum[slot] += t_ - t_prev;                                                     \
+        t_prev = t_;                                                                        \
+    } while (0)
+#else
+#define CCX_STAMP(slot) do { } while (0)
+#endif
+
+constexpr int kActBatch = 16;  // env-steps of actions fetched per global-load burst
+
 template <int GLOG, bool PAIR>
 __global__ void __launch_bounds__(256)
 rollout_kernel(const KParams p, const KState st, const uint8_t* __restrict__ actions,
@@ -182,6 +217,8 @@ rollout_kernel(const KParams p, const KState st, const uint8_t* __restrict__ act
     const bool boarding = i < p.Nb;
     const int dest_y = boarding ? p.bdy : p.edy;
     const mask_t full = full_mask<GLOG>();
+    const mask_t lo = low_mask<mask_t>(i);
+    const mask_t later = ~lo & ~(mask_t(1) << i);
 
     // LDS carve-up: [WaveLds x waves_per_block][u16 table]
     WaveLds* wl = reinterpret_cast<WaveLds*>(smem) + wib;
@@ -209,206 +246,282 @@ rollout_kernel(const KParams p, const KState st, const uint8_t* __restrict__ act
         stepc = st.step_count[env];
         episode = st.episode[env];
     }
+    // final write-back addresses, parked in VGPRs for the duration of the loop
+    int32_t* const fx = in_vgpr(st.x + idx);
+    int32_t* const fy = in_vgpr(st.y + idx);
+    uint8_t* const fact = in_vgpr(st.active + idx);
+    uint8_t* const fterm = in_vgpr(st.terminated + idx);
+    uint8_t* const ftrunc = in_vgpr(st.truncated + idx);
+    int32_t* const fstep = in_vgpr(st.step_count + env);
+    int32_t* const fepi = in_vgpr(st.episode + env);
+    unsigned long long* const ctr = in_vgpr(counters);
+
+    // reward constants, selected once (rewards.py:44-182):  r = c1 ? rA : c2 ? rB : c3 ? rC : d*rF
+    const int rmode = p.reward_mode;
+    const double rA = in_vgpr(rmode == CCX_K_REWARD_BINARY ? p.r_nogoal
+                              : rmode == CCX_K_REWARD_CONSTANT_NEGATIVE ? p.r_pen : p.r_dest);
+    const double rB = in_vgpr(p.r_door);
+    const double rC = in_vgpr(p.r_area);
+    const double rF = in_vgpr(p.r_f);
+
     // reset-pool cursor of this env: entry (global_env + episode*total) mod P, advanced by
-    // total mod P per episode; the NEXT placement is prefetched right after every reset.
-    uint32_t pool_idx = 0, px = 0, py = 0;
+    // total mod P per episode; the NEXT placement is prefetched right after every reset and only
+    // decoded when it is consumed (so no wait sits behind the load).
+    uint32_t pool_idx = 0, pnext = 0;
+    int px = 0, py = 0;
+    bool pnext_pending = false;   // pnext holds a load that has not been decoded into px/py yet
     const bool use_pool = auto_reset && pool != nullptr && p.pool_size > 0;
+    const uint32_t pool_size = (uint32_t)p.pool_size, pool_stride = (uint32_t)p.pool_stride;
+    const uint8_t* const pool_v = pool;   // stays a global-address-space pointer (SGPR pair)
     if (use_pool && valid) {
         unsigned long long P = (unsigned long long)p.pool_size;
         unsigned long long gi = (unsigned long long)(p.env_offset + env) % P;
         unsigned long long ep = (unsigned long long)(episode + 1) % P;
         pool_idx = (uint32_t)((gi + ep * (unsigned long long)p.pool_stride) % P);
-        uint16_t v = *reinterpret_cast<const uint16_t*>(pool + ((size_t)pool_idx * N + i) * 2);
-        px = v & 0xFF;
-        py = v >> 8;
+        pnext = *reinterpret_cast<const uint16_t*>(pool_v + ((size_t)pool_idx * N + i) * 2);
+        pnext_pending = true;
     }
 
-    // ---- action prefetch queue (depth 4) -----------------------------------------------------
-    constexpr int PF = 4;
-    uint32_t aq[PF];
-#pragma unroll
-    for (int d = 0; d < PF; ++d)
-        aq[d] = (valid && d < K) ? actions[(size_t)d * EN + idx] : (uint32_t)CCX_K_ABSENT;
+    // per-lane output cursors, advanced by one step's stride per iteration
+    double* rew_p = out.reward ? out.reward + idx : nullptr;
+    uint8_t* af_p = out.agent_flags ? out.agent_flags + idx : nullptr;
+    uint8_t* ef_p = out.env_flags ? out.env_flags + env : nullptr;
+    float* obs_p = want_obs ? out.obs + (size_t)env0 * N * L : nullptr;
+    const size_t obs_stride = EN * (size_t)L;
+    const uint8_t* act_p = actions + idx;
+    const uint8_t* ord_p = order ? order + idx : nullptr;
 
     uint32_t c_moves = 0, c_arrivals = 0, c_live = 0, c_episodes = 0;
+#ifdef CCX_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#endif
 
-    for (int s = 0; s < K; ++s) {
-        const uint32_t a = aq[0];
+    // ---- actions: bursts of kActBatch steps, 4 bits per step in a u64 --------------------------
+    // One s_waitcnt vmcnt per burst instead of one per step (vmcnt also counts the stores).
+    // Loads are unconditional (steps past K re-read the last valid step) and addressed from a
+    // VGPR stride, so the burst is straight-line code with no scalar address table.
+    uint32_t araw[kActBatch];
+    const size_t EN_v = in_vgpr(EN);
+    auto fetch_actions = [&](int s_first) {
+        const int last = K - 1 - s_first;   // >= 0 whenever this is called
 #pragma unroll
-        for (int d = 0; d + 1 < PF; ++d) aq[d] = aq[d + 1];
-        aq[PF - 1] = (valid && s + PF < K) ? actions[(size_t)(s + PF) * EN + idx]
-                                           : (uint32_t)CCX_K_ABSENT;
-
-        // ---- move rank of this agent (dict order of action_dict, collectivecrossing.py:197)
-        int rank = i;
-        if (order != nullptr) {
-            uint32_t ok_ = valid ? order[(size_t)s * EN + idx] : (uint32_t)i;  // agent moved i-th
-            wl->xch[gbase + (ok_ & (G - 1))] = (uint32_t)i;
-            wave_lds_sync();
-            rank = (int)wl->xch[lane];
-            wave_lds_sync();
+        for (int d = 0; d < kActBatch; ++d) {
+            const int dd = d < last ? d : last;
+            araw[d] = valid ? (uint32_t)act_p[(size_t)dd * EN_v] : CCX_K_ABSENT;
         }
+        act_p += (size_t)kActBatch * EN_v;
+    };
+    fetch_actions(0);
 
-        stepc += 1;  // collectivecrossing.py:188
-
-        // ---- 1. proposal (collectivecrossing.py:371-376, 509-534; 565-588 adds nothing)
-        const int dx = (a == 0u) - (a == 2u);
-        const int dy = (a == 1u) - (a == 3u);
-        const int nx = x + dx, ny = y + dy;
-        bool ok = valid && active && (a < 4u);
-        ok = ok && ((unsigned)nx <= (unsigned)p.W) && ((unsigned)ny <= (unsigned)p.H);
-        ok = ok && !(ny == p.div && !(p.dl < nx && nx < p.dr));
-        ok = ok && !(ny >= p.div && !(p.tl < nx && nx < p.tr));
-        const uint32_t curkey = (valid && active) ? (uint32_t)(x | (y << 8)) : 0x8000u;
-        const uint32_t propkey = ok ? (uint32_t)(nx | (ny << 8)) : 0xFFFFu;
-        wl->xch[gbase + rank] = curkey | (propkey << 16);
-        wave_lds_sync();
-
-        // ---- 2. this lane now plays move-rank i of its group
-        const uint32_t own = wl->xch[lane];
-        const uint32_t myprop = own >> 16;
-        mask_t call = 0, pall = 0;
-#pragma unroll 8
-        for (int k2 = 0; k2 < N; ++k2) {
-            const uint32_t v = wl->xch[gbase + k2];
-            call |= (mask_t)((v & 0xFFFFu) == myprop) << k2;
-            pall |= (mask_t)((v >> 16) == myprop) << k2;
+    for (int s0 = 0; s0 < K; s0 += kActBatch) {
+        // the burst issued one batch ago is consumed here: ONE vmcnt wait per kActBatch steps
+        unsigned long long apack = 0;
+#pragma unroll
+        for (int d = 0; d < kActBatch; ++d)
+            apack |= (unsigned long long)(araw[d] & 0xFu) << (4 * d);   // 255 -> 15: no move
+        apack = in_vgpr(apack);
+        if (pnext_pending) {   // decode behind the wait that just happened: costs nothing
+            px = (int)(pnext & 0xFFu);
+            py = (int)(pnext >> 8);
+            pnext_pending = false;
         }
-        const mask_t lo = low_mask<mask_t>(i);
-        const mask_t Cm = call & lo, Pm = pall & lo;
-        const bool blocked_later = (call & ~lo & ~(mask_t(1) << i)) != 0;  // later ranks: old cells
-        const bool okr = (myprop != 0xFFFFu) && !blocked_later;
+        __builtin_amdgcn_sched_barrier(0);   // keep the next burst BEHIND the wait above
+        if (s0 + kActBatch < K) fetch_actions(s0 + kActBatch);
+        __builtin_amdgcn_sched_barrier(0);
+        const int dmax = (K - s0) < kActBatch ? (K - s0) : kActBatch;
+        CCX_STAMP(0);   // burst wait + pack + next burst issue
 
-        // ---- 3. ballot fixed point over "who moved"
-        uint64_t b = __ballot(okr && (Cm == 0));
-        for (int it = 1; it < N; ++it) {
-            const mask_t M = group_bits<GLOG>(b, lane);
-            const uint64_t b2 = __ballot(okr && (((M & Pm) | (~M & Cm)) == 0));
-            if (b2 == b) break;
-            b = b2;
-        }
-        wave_lds_sync();  // xch is rewritten next step
-        const bool moved = (group_bits<GLOG>(b, lane) >> rank) & 1;
-        if (moved) {  // collectivecrossing.py:408
-            x = nx;
-            y = ny;
-        }
-        c_moves += moved;
+        for (int d = 0; d < dmax; ++d) {
+            const uint32_t a = (uint32_t)(apack >> (4 * d)) & 0xFu;
 
-        // ---- 4. tail: deactivate, reward, terminated, truncated, flags (:210-241)
-        const bool at_dest = (y == dest_y);                       // :663-683
-        const bool arrive = valid && active && at_dest;           // :210-212
-        active = active && !arrive;
-        c_arrivals += arrive;
-        const bool live = valid && !(term || trunc);              // rewards.py:64, truncateds.py:56
-        c_live += live;
-        const bool in_area = (y >= p.div) && (p.tl <= x) && (x <= p.tr);         // :551-554
-        const bool at_door = (y == p.div) && (x == p.dl - 1 || x == p.dr + 1);   // :556-563
-
-        double r = 0.0;
-        if (p.reward_mode == CCX_K_REWARD_DEFAULT) {              // rewards.py:44-99
-            const int adx = x > p.dc ? x - p.dc : p.dc - x;
-            if (boarding) {
-                const long long d = (long long)adx + (long long)(p.div - y);
-                r = at_dest ? p.r_dest : at_door ? p.r_door : in_area ? p.r_area
-                            : (double)(-d) * p.r_f;
-            } else {
-                const long long d = (long long)adx + (long long)(y - p.div);
-                r = at_dest ? p.r_dest : !in_area ? p.r_area : (double)d * p.r_f;
+            // ---- move rank of this agent (dict order of action_dict, collectivecrossing.py:197)
+            int rank = i;
+            if (ord_p != nullptr) {
+                uint32_t ok_ = valid ? (uint32_t)*ord_p : (uint32_t)i;  // agent moved i-th
+                ord_p += EN;
+                wl->xch[gbase + (ok_ & (G - 1))] = (uint32_t)i;
+                wave_lds_sync();
+                rank = (int)wl->xch[lane];
+                wave_lds_sync();
             }
-        } else if (p.reward_mode == CCX_K_REWARD_SIMPLE_DISTANCE) {  // rewards.py:105-129
-            const long long d = y > dest_y ? y - dest_y : dest_y - y;
-            r = (double)(-d) * p.r_f;   // negate the INTEGER first: d == 0 gives +0.0
-        } else if (p.reward_mode == CCX_K_REWARD_BINARY) {        // rewards.py:135-159
-            r = p.r_nogoal;
-        } else {                                                   // rewards.py:165-182
-            r = p.r_pen;
-        }
-        if (!live) r = 0.0;
 
-        bool term_out = at_dest;                                   // terminateds.py:66-82
-        const mask_t dest_bits = group_bits<GLOG>(__ballot(at_dest || !valid), lane);
-        if (p.term_mode == CCX_K_TERM_ALL) term_out = (dest_bits == full);   // terminateds.py:40-60
-        const bool trunc_out = live && (stepc >= p.max_steps);     // truncateds.py:40-61
-        const bool done_now = (term_out && !term) || (trunc_out && !trunc);  // :229-241
-        term = term || term_out;
-        trunc = trunc || trunc_out;
-        const bool emit = done_now || !(term || trunc);            // :243, :763-767
+            stepc += 1;  // collectivecrossing.py:188
+            CCX_STAMP(7);   // loop overhead / order path
 
-        const mask_t term_bits = (p.term_mode == CCX_K_TERM_ALL)
-                                     ? (term_out ? full : mask_t(0))
-                                     : dest_bits;
-        const bool all_term = (term_bits == full) && (N > 0);      // :256
-        const mask_t live_bits = group_bits<GLOG>(__ballot(live), lane);
-        const mask_t tr_bits = group_bits<GLOG>(__ballot(!live || trunc_out), lane);
-        const bool all_trunc = (live_bits != 0) && (tr_bits == full);  // :257
-        uint32_t ef = (all_term ? CCX_K_EF_ALL_TERM : 0u) | (all_trunc ? CCX_K_EF_ALL_TRUNC : 0u);
-
-        const uint32_t af = (term_out ? 0x01u : 0u) | (trunc_out ? 0x02u : 0u) |
-                            (live ? 0x04u : 0u) | (emit ? 0x08u : 0u) | (in_area ? 0x10u : 0u) |
-                            (at_door ? 0x20u : 0u) | (active ? 0x40u : 0u) | (at_dest ? 0x80u : 0u);
-
-        // ---- 5. outputs
-        const size_t so = (size_t)s * EN + idx;
-        if (valid) {
-            if (out.reward) out.reward[so] = r;
-            if (out.agent_flags) out.agent_flags[so] = (uint8_t)af;
-        }
-        if (want_obs) {
-            wl->slot[lane] = make_float4((float)x, (float)y, boarding ? 0.0f : 1.0f,
-                                         active ? 1.0f : 0.0f);
+            // ---- 1. proposal (collectivecrossing.py:371-376, 509-534; 565-588 adds nothing)
+            const int dx = (a == 0u) - (a == 2u);
+            const int dy = (a == 1u) - (a == 3u);
+            const int nx = x + dx, ny = y + dy;
+            bool ok = valid && active && (a < 4u);
+            ok = ok && ((unsigned)nx <= (unsigned)p.W) && ((unsigned)ny <= (unsigned)p.H);
+            ok = ok && !(ny == p.div && !(p.dl < nx && nx < p.dr));
+            ok = ok && !(ny >= p.div && !(p.tl < nx && nx < p.tr));
+            const uint32_t curkey = (valid && active) ? (uint32_t)(x | (y << 8)) : 0x8000u;
+            const uint32_t propkey = ok ? (uint32_t)(nx | (ny << 8)) : 0xFFFFu;
+            wl->xch[gbase + rank] = curkey | (propkey << 16);
             wave_lds_sync();
-            float* dst = out.obs + ((size_t)s * p.E + env0) * (size_t)N * L;
-            emit_obs<PAIR>(wl, table, dst, units, lane);
-            wave_lds_sync();
-        }
 
-        // ---- 6. auto-reset from the pool (reset() :97-150 with host-computed placements)
-        const bool do_reset = use_pool && valid_env && (ef != 0u);
-        if (do_reset) {
-            ef |= CCX_K_EF_RESET;
-            episode += 1;
-            stepc = 0;
-            c_episodes += (i == 0);
+            // ---- 2. this lane now plays move-rank i of its group.  Entries of unused lanes hold
+            //         cur 0x8000 / prop 0xFFFF and can never match a real proposal.
+            const uint32_t myprop = wl->xch[lane] >> 16;
+            mask_t call = 0, pall = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < G; ++k2) {
+                const uint32_t v = wl->xch[gbase + k2];
+                call |= (mask_t)((v & 0xFFFFu) == myprop) << k2;
+                pall |= (mask_t)((v >> 16) == myprop) << k2;
+            }
+            CCX_STAMP(1);   // proposal + LDS exchange + pair masks
+            const mask_t Cm = call & lo, Pm = pall & lo;
+            const bool okr = (myprop != 0xFFFFu) && ((call & later) == 0);  // later ranks: old cells
+
+            // ---- 3. ballot fixed point over "who moved"
+            uint64_t b = __ballot(okr && (Cm == 0));
+            for (int it = 1; it < N; ++it) {
+                const mask_t M = group_bits<GLOG>(b, lane);
+                const uint64_t b2 = __ballot(okr && (((M & Pm) | (~M & Cm)) == 0));
+                if (b2 == b) break;
+                b = b2;
+            }
+            wave_lds_sync();  // xch is rewritten next step
+            const bool moved = (group_bits<GLOG>(b, lane) >> rank) & 1;
+            if (moved) {  // collectivecrossing.py:408
+                x = nx;
+                y = ny;
+            }
+            c_moves += moved;
+            CCX_STAMP(2);   // ballot fixed point + position update
+
+            // ---- 4. tail: deactivate, reward, terminated, truncated, flags (:210-241)
+            const bool at_dest = (y == dest_y);                       // :663-683
+            const bool arrive = valid && active && at_dest;           // :210-212
+            active = active && !arrive;
+            c_arrivals += arrive;
+            const bool live = valid && !(term || trunc);              // rewards.py:64, truncateds.py:56
+            c_live += live;
+            const bool in_area = (y >= p.div) && (p.tl <= x) && (x <= p.tr);         // :551-554
+            const bool at_door = (y == p.div) && (x == p.dl - 1 || x == p.dr + 1);   // :556-563
+
+            // rewards.py:44-182.  Distances are integers and the reference negates the INTEGER
+            // before the one f64 multiply, so d == 0 gives +0.0 (never -0.0).
+            bool c1 = true, c2 = false, c3 = false;
+            int sd = 0;
+            if (rmode == CCX_K_REWARD_DEFAULT) {
+                const int adx = x > p.dc ? x - p.dc : p.dc - x;
+                c1 = at_dest;
+                c2 = boarding && at_door;
+                c3 = boarding ? in_area : !in_area;
+                sd = boarding ? -(adx + (p.div - y)) : (adx + (y - p.div));
+            } else if (rmode == CCX_K_REWARD_SIMPLE_DISTANCE) {
+                c1 = false;
+                sd = -(y > dest_y ? y - dest_y : dest_y - y);
+            }
+            double r = c1 ? rA : c2 ? rB : c3 ? rC : (double)sd * rF;
+            if (!live) r = 0.0;
+
+            bool term_out = at_dest;                                   // terminateds.py:66-82
+            const mask_t dest_bits = group_bits<GLOG>(__ballot(at_dest || !valid), lane);
+            if (p.term_mode == CCX_K_TERM_ALL) term_out = (dest_bits == full);   // terminateds.py:40-60
+            const bool trunc_out = live && (stepc >= p.max_steps);     // truncateds.py:40-61
+            const bool done_now = (term_out && !term) || (trunc_out && !trunc);  // :229-241
+            term = term || term_out;
+            trunc = trunc || trunc_out;
+            const bool emit = done_now || !(term || trunc);            // :243, :763-767
+
+            const mask_t term_bits = (p.term_mode == CCX_K_TERM_ALL)
+                                         ? (term_out ? full : mask_t(0))
+                                         : dest_bits;
+            const bool all_term = (term_bits == full);                 // :256
+            const mask_t live_bits = group_bits<GLOG>(__ballot(live), lane);
+            const mask_t tr_bits = group_bits<GLOG>(__ballot(!live || trunc_out), lane);
+            const bool all_trunc = (live_bits != 0) && (tr_bits == full);  // :257
+            uint32_t ef = (all_term ? CCX_K_EF_ALL_TERM : 0u) | (all_trunc ? CCX_K_EF_ALL_TRUNC : 0u);
+
+            const uint32_t af = (term_out ? 0x01u : 0u) | (trunc_out ? 0x02u : 0u) |
+                                (live ? 0x04u : 0u) | (emit ? 0x08u : 0u) | (in_area ? 0x10u : 0u) |
+                                (at_door ? 0x20u : 0u) | (active ? 0x40u : 0u) | (at_dest ? 0x80u : 0u);
+
+            CCX_STAMP(3);   // tail: reward / flags / ballots
+            // ---- 5. outputs
             if (valid) {
-                x = (int)px;
-                y = (int)py;
-                active = true;
-                term = false;
-                trunc = false;
-                pool_idx += (uint32_t)p.pool_stride;
-                if (pool_idx >= (uint32_t)p.pool_size) pool_idx -= (uint32_t)p.pool_size;
-                uint16_t v = *reinterpret_cast<const uint16_t*>(pool + ((size_t)pool_idx * N + i) * 2);
-                px = v & 0xFF;
-                py = v >> 8;
+                if (rew_p) {
+                    *rew_p = r;
+                    rew_p += EN;
+                }
+                if (af_p) {
+                    *af_p = (uint8_t)af;
+                    af_p += EN;
+                }
             }
+            CCX_STAMP(4);   // reward + flag stores
+            if (want_obs) {
+                wl->slot[lane] = make_float4((float)x, (float)y, boarding ? 0.0f : 1.0f,
+                                             active ? 1.0f : 0.0f);
+                wave_lds_sync();
+                emit_obs<PAIR>(wl, table, obs_p, units, lane);
+                obs_p += obs_stride;
+                wave_lds_sync();
+            }
+
+            CCX_STAMP(5);   // observation gather + stores
+            // ---- 6. auto-reset from the pool (reset() :97-150 with host-computed placements)
+            const bool do_reset = use_pool && valid_env && (ef != 0u);
+            if (do_reset) {
+                ef |= CCX_K_EF_RESET;
+                episode += 1;
+                stepc = 0;
+                c_episodes += (i == 0);
+                if (valid) {
+                    if (pnext_pending) {   // second reset inside one action burst (rare): wait here
+                        asm volatile("; rare: reset twice within one action burst");
+                        px = (int)(pnext & 0xFFu);
+                        py = (int)(pnext >> 8);
+                    }
+                    x = px;
+                    y = py;
+                    active = true;
+                    term = false;
+                    trunc = false;
+                    pool_idx += pool_stride;
+                    if (pool_idx >= pool_size) pool_idx -= pool_size;
+                    pnext = *reinterpret_cast<const uint16_t*>(pool_v + ((size_t)pool_idx * N + i) * 2);
+                    pnext_pending = true;
+                }
+            }
+            if (ef_p && valid_env && i == 0) *ef_p = (uint8_t)ef;
+            if (ef_p) ef_p += p.E;
+            CCX_STAMP(6);   // auto-reset + env flag store
         }
-        if (out.env_flags && valid_env && i == 0) out.env_flags[(size_t)s * p.E + env] = (uint8_t)ef;
     }
+#ifdef CCX_STAMPS
+    if (ctr && wave == 0 && lane == 0)
+        for (int q = 0; q < 8; ++q) atomicAdd(&ctr[8 + q], stamp_sum[q]);
+#endif
 
     // ---- registers -> state ------------------------------------------------------------------
     if (valid) {
-        st.x[idx] = x;
-        st.y[idx] = y;
-        st.active[idx] = active;
-        st.terminated[idx] = term;
-        st.truncated[idx] = trunc;
+        *fx = x;
+        *fy = y;
+        *fact = active;
+        *fterm = term;
+        *ftrunc = trunc;
     }
     if (valid_env && i == 0) {
-        st.step_count[env] = stepc;
-        st.episode[env] = episode;
+        *fstep = stepc;
+        *fepi = episode;
     }
-    if (counters) {
+    if (ctr) {
         const uint32_t nenv = wave_sum_u32((valid_env && i == 0) ? 1u : 0u);
         const uint32_t moves = wave_sum_u32(c_moves), arrivals = wave_sum_u32(c_arrivals);
         const uint32_t lives = wave_sum_u32(c_live), eps = wave_sum_u32(c_episodes);
         if (lane == 0 && nenv) {
-            atomicAdd(&counters[0], (unsigned long long)nenv * (unsigned long long)K);
-            atomicAdd(&counters[1], (unsigned long long)nenv * (unsigned long long)K * N);
-            atomicAdd(&counters[2], (unsigned long long)lives);
-            atomicAdd(&counters[3], (unsigned long long)eps);
-            atomicAdd(&counters[4], (unsigned long long)moves);
-            atomicAdd(&counters[5], (unsigned long long)arrivals);
+            atomicAdd(&ctr[0], (unsigned long long)nenv * (unsigned long long)K);
+            atomicAdd(&ctr[1], (unsigned long long)nenv * (unsigned long long)K * N);
+            atomicAdd(&ctr[2], (unsigned long long)lives);
+            atomicAdd(&ctr[3], (unsigned long long)eps);
+            atomicAdd(&ctr[4], (unsigned long long)moves);
+            atomicAdd(&ctr[5], (unsigned long long)arrivals);
         }
     }
 }

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does one env-step spend its cycles?  Loads the -DCCX_STAMPS build of libccx
+(make -C collectivecrossing_amd/csrc stamps) and prints the per-segment s_memtime sums of wave 0.
+Shares, not absolute times (the stamps serialise the segments)."""
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+
+from collectivecrossing_amd import _lib  # noqa: E402
+
+_lib.LIB_PATH = ROOT / "collectivecrossing_amd" / "csrc" / "_diag" / "libccx_stamps.so"
+import ctypes as C  # noqa: E402
+
+from bench import c2_config  # noqa: E402
+from collectivecrossing_amd.batched import BatchedCollectiveCrossing  # noqa: E402
+from collectivecrossing_amd.reset import build_reset_pool  # noqa: E402
+
+lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+E, K, N = 4096, 256, 8
+cfg = c2_config()
+env = BatchedCollectiveCrossing(cfg, E)
+if lanes:
+    env.set_launch_shape(lanes, 0)
+env.set_reset_pool(build_reset_pool(cfg, 0, 1024))
+env.reset_from_pool()
+acts = torch.randint(0, 5, (K, E, N), dtype=torch.uint8, device=env.device)
+traj = env.alloc_rollout(K)
+env.rollout(acts, auto_reset=True, out=traj)
+env.zero_counters()
+env.rollout(acts, auto_reset=True, out=traj)
+env.synchronize()
+p = C.c_void_p()
+env._lib.ccx_counters_device_ptr(env._h, C.byref(p))
+from collectivecrossing_amd.batched import _device_view_i64  # noqa: E402
+
+c = _device_view_i64(p.value, 16, env.device).cpu().tolist()
+names = ["0 burst wait+pack+issue (per 16 steps)", "1 proposal+exchange+pair masks", "2 ballot fixed point",
+         "3 tail", "4 reward/flag stores", "5 obs gather+stores", "6 reset+env flag", "7 loop top/order"]
+tot = sum(c[8:16])
+print(f"launch shape {env.launch_shape()}  kernel {env.last_launch_ms():.3f} ms for {K} steps (stamped build)")
+for n, v in zip(names, c[8:16]):
+    print(f"  {n:45s} {v / K:9.1f} ticks/step  {100.0 * v / tot:5.1f}%")
+print(f"  total {tot / K:.1f} ticks/step (s_memtime ticks; 100 MHz realtime or shader clock, see guide)")
