@@ -49,6 +49,7 @@ struct ccx_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     ccx::KState st{};
+    unsigned long long* cell_info = nullptr; // per-cell geometry table (see ccx_kernels.hip: CellInfo)
     unsigned long long* counters = nullptr;  // 6 x u64 (+ 10 spare words used by diagnostic builds)
     const uint8_t* pool = nullptr;
     int64_t pool_size = 0;
@@ -61,9 +62,50 @@ struct ccx_handle {
 
 namespace {
 
-// Default launch shape.  The per-wave instruction stream does not depend on how many lanes carry
-// agents, so for small batches fewer envs per wave (more waves) uses more of the 1024 SIMDs;
-// once every SIMD has a couple of waves, fuller waves are cheaper.
+// Per-cell geometry table of the padded grid (layout: ccx_kernels.hip, struct CellInfo).  This is
+// config lowering, done once per handle: the reference evaluates the same predicates per agent
+// per step (collectivecrossing.py:509-534, 551-563, 663-683; rewards.py:44-182).
+std::vector<unsigned long long> build_cell_table(const ccx_params& p) {
+    const int Wp = p.width + 3, Hp = p.height + 3;
+    const int dc = (p.door_left + p.door_right) / 2;
+    std::vector<unsigned long long> tab((size_t)Wp * Hp, 0ull);
+    for (int y = -1; y <= p.height + 1; ++y)
+        for (int x = -1; x <= p.width + 1; ++x) {
+            const bool inside = x >= 0 && x <= p.width && y >= 0 && y <= p.height;
+            if (!inside) continue;  // border: VALID = 0, never occupied
+            bool valid = true;
+            if (y == p.division_y && !(p.door_left < x && x < p.door_right)) valid = false;
+            if (y >= p.division_y && !(p.tram_left < x && x < p.tram_right)) valid = false;
+            const bool in_area = y >= p.division_y && p.tram_left <= x && x <= p.tram_right;
+            const bool at_door = y == p.division_y && (x == p.door_left - 1 || x == p.door_right + 1);
+            const bool dest_b = y == p.boarding_dest_y, dest_e = y == p.exiting_dest_y;
+            const int adx = x > dc ? x - dc : dc - x;
+            unsigned cls_b = 1, cls_e = 1;   // binary / constant_negative: always the constant rA
+            int sd_b = 0, sd_e = 0;
+            if (p.reward_mode == CCX_REWARD_DEFAULT) {
+                cls_b = dest_b ? 1 : at_door ? 2 : in_area ? 3 : 0;
+                cls_e = dest_e ? 1 : !in_area ? 3 : 0;
+                sd_b = -(adx + (p.division_y - y));
+                sd_e = adx + (y - p.division_y);
+            } else if (p.reward_mode == CCX_REWARD_SIMPLE_DISTANCE) {
+                cls_b = cls_e = 0;
+                sd_b = -(y > p.boarding_dest_y ? y - p.boarding_dest_y : p.boarding_dest_y - y);
+                sd_e = -(y > p.exiting_dest_y ? y - p.exiting_dest_y : p.exiting_dest_y - y);
+            }
+            unsigned lo = (valid ? 1u : 0u) | (in_area ? 0x10u : 0u) | (at_door ? 0x20u : 0u) |
+                          ((dest_b ? 1u : 0u) << 8) | (cls_b << 9) | ((dest_e ? 1u : 0u) << 12) |
+                          (cls_e << 13) | ((unsigned)x << 16) | ((unsigned)y << 24);
+            unsigned hi = ((unsigned)sd_b & 0xFFFFu) | (((unsigned)sd_e & 0xFFFFu) << 16);
+            tab[(size_t)(y + 1) * Wp + (x + 1)] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+        }
+    return tab;
+}
+
+// Default launch shape.  A tile (EW envs) is served by a sim wave and, when outputs are written,
+// a writer wave on another SIMD; one step of a tile is a latency chain of ~1.5k cycles whatever
+// EW is, so the batch should be cut into at least ~512 tiles (1024 waves = one per SIMD of the
+// 256 CUs) before tiles are made fuller.  Measured on 4096 envs x 8 agents: 64 lanes/wave
+// (512 tiles) 0.252 ms per 250 steps, 32 lanes 0.280 ms, 16 lanes 0.344 ms.
 void choose_shape(ccx_handle* h) {
     const int glog = ceil_log2(h->N);
     const int G = 1 << glog;
@@ -72,14 +114,14 @@ void choose_shape(ccx_handle* h) {
     if (h->lanes_per_wave > 0) {
         ew = h->lanes_per_wave / G;
     } else {
-        const int target_waves = 2048;
+        const int target_tiles = 512;
         ew = max_ew;
-        while (ew > 1 && (h->E + ew - 1) / ew < target_waves) ew >>= 1;
+        while (ew > 1 && (h->E + ew - 1) / ew < target_tiles) ew >>= 1;
     }
     if (ew < 1) ew = 1;
     if (ew > max_ew) ew = max_ew;
     const int waves = (h->E + ew - 1) / ew;
-    int wpb = h->waves_per_block > 0 ? h->waves_per_block : (waves > 4096 ? 4 : 1);
+    int wpb = h->waves_per_block > 0 ? h->waves_per_block : (waves > 8192 ? 2 : 1);
     if (wpb > 4) wpb = 4;
     ccx::LaunchShape& s = h->shape;
     s.glog = glog;
@@ -87,8 +129,11 @@ void choose_shape(ccx_handle* h) {
     s.waves_per_block = wpb;
     s.num_blocks = (waves + wpb - 1) / wpb;
     const int units = ew * h->N * (3 + 2 * h->N);
-    size_t lds = (size_t)wpb * 1312u + (size_t)(units + 2) * 2u;
-    s.lds_bytes = (lds + 15u) & ~(size_t)15u;
+    const size_t table = (size_t)(units + 2) * 2u;
+    const size_t cells = (size_t)(h->params.width + 3) * (size_t)(h->params.height + 3);
+    s.lds_bytes_observe = ((size_t)wpb * 1312u + table + 15u) & ~(size_t)15u;      // WaveLds
+    s.lds_bytes = ((cells * 8u + 15u) & ~(size_t)15u) +
+                  (((size_t)wpb * 3360u + table + 15u) & ~(size_t)15u);             // TileLds
 
     ccx::KParams& k = h->kp;
     const ccx_params& p = h->params;
@@ -145,8 +190,8 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     CCX_HIP(hipSetDevice(h->device));
     int rc = begin_timed(h);
     if (rc) return rc;
-    hipError_t e = ccx::launch_rollout(h->shape, h->stream, h->kp, h->st, actions, order, K,
-                                       auto_reset, h->pool, out, h->counters);
+    hipError_t e = ccx::launch_rollout(h->shape, h->stream, h->kp, h->st, h->cell_info, actions,
+                                       order, K, auto_reset, h->pool, out, h->counters);
     if (e != hipSuccess) return fail(CCX_EHIP, "rollout kernel launch failed: %s", hipGetErrorString(e));
     return end_timed(h);
 }
@@ -212,6 +257,11 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     alloc((void**)&h->st.step_count, (size_t)h->E * 4);
     alloc((void**)&h->st.episode, (size_t)h->E * 4);
     alloc((void**)&h->counters, 16 * sizeof(unsigned long long));
+    const std::vector<unsigned long long> cell_tab = build_cell_table(*params);
+    alloc((void**)&h->cell_info, cell_tab.size() * sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipMemcpy(h->cell_info, cell_tab.data(), cell_tab.size() * sizeof(unsigned long long),
+                      hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_stop);
     if (e == hipSuccess) e = hipMemsetAsync(h->st.x, 0, en * 4, h->stream);
@@ -245,6 +295,7 @@ void ccx_destroy(ccx_handle* h) {
     (void)hipFree(h->st.step_count);
     (void)hipFree(h->st.episode);
     (void)hipFree(h->counters);
+    (void)hipFree(h->cell_info);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
     delete h;

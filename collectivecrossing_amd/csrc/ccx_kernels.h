@@ -49,11 +49,13 @@ struct LaunchShape {
     int envs_per_wave;    // EW
     int waves_per_block;
     int num_blocks;
-    size_t lds_bytes;
+    size_t lds_bytes;        // rollout kernel: cell table + per-wave tiles + obs table
+    size_t lds_bytes_observe;  // observe kernel: per-wave tiles + obs table
 };
 
 hipError_t launch_rollout(const LaunchShape& ls, hipStream_t stream, const KParams& p,
-                          const KState& st, const uint8_t* actions, const uint8_t* order, int K,
+                          const KState& st, const unsigned long long* cell_info,
+                          const uint8_t* actions, const uint8_t* order, int K,
                           int auto_reset, const uint8_t* pool, const KOut& out,
                           unsigned long long* counters);
 hipError_t launch_observe(const LaunchShape& ls, hipStream_t stream, const KParams& p,

@@ -5,27 +5,36 @@
 // (rewards.py:44-182, terminateds.py:40-82, truncateds.py:40-61, observations.py:43-94).
 //
 // Mapping (wave64): one LANE per (env, agent).  An env owns a group of G = 2^GLOG >= N consecutive
-// lanes, a wavefront carries EW <= 64/G envs and keeps their state in registers for all K steps of
-// a rollout; waves never talk to each other (no barrier in the step loop, no inter-workgroup
-// traffic), so the grid is embarrassingly parallel over env tiles.
+// lanes; a SIM wavefront carries EW <= 64/G envs and keeps their state in registers for all K
+// steps of a rollout.  Env tiles never talk to each other (no inter-workgroup traffic).
+//
+// A workgroup is a PAIR of wavefronts per env tile, split by role along the reference's own phase
+// boundary (collectivecrossing.py:197-212 vs :214-261):
+//   * the SIM wave does the state transition: action decode, ordered move resolution, arrival /
+//     termination / truncation flags, auto-reset.  It issues no global stores at all; per step it
+//     hands 16 bytes per lane (cell word, distance word, flag byte, env byte) to its partner
+//     through a double-buffered LDS tile and one s_barrier.
+//   * the WRITER wave materialises the outputs of that step: the f64 reward, the flag bytes and
+//     the observation rows (the byte-dominant part, 4*(6+4N) B per agent-step).  It stages
+//     (x, y, type, active) as float4 per agent in LDS; the tile's rows form ONE contiguous region
+//     of the [E][N][L] output, written with full-width global_store_dwordx4 whose two 8-byte
+//     halves come from LDS addresses that never change (kept in VGPRs / a u16 LDS table).
+//   The two waves sit on different SIMDs of one CU, so a step costs max(sim, writer) instead of
+//   the sum, and the stores drain asynchronously: the writer never waits on vmcnt.
 //
 // Ordered move resolution without a serial agent loop ("agent k sees earlier agents at their new
 // cell and later agents at their old cell", collectivecrossing.py:197-202,536-541):
-//   1. every lane proposes its target cell in parallel (bounds + wall predicate, closed form);
+//   1. every lane proposes its target cell in parallel; validity of the target (bounds, walls,
+//      door) and everything else the step needs to know about a cell is ONE ds_read_b64 from a
+//      per-cell table precomputed on the host (see "per-cell geometry table" below);
 //   2. proposals are exchanged through a 256-byte LDS tile indexed by move RANK, so lane k of a
 //      group plays "the agent moved k-th";
 //   3. each rank k builds two bit masks over earlier ranks k' < k:  P[k'] = prop_k' == prop_k,
 //      C[k'] = active_k' && cur_k' == prop_k, and tests later ranks' current cells once;
-//   4. with M = mask of earlier ranks that DID move, rank k moves iff ((M & P) | (~M & C)) == 0,
-//      one v_bfi_b32.  M is a wave ballot (v_cmp writes the lane mask to SGPRs for free); F(M)
-//      has a unique fixed point reached in <= N rounds (bit k of F depends on bits < k only), and
-//      the loop exits as soon as two consecutive ballots agree -- typically after 2 rounds.
-//
-// Observation gather (the byte-dominant part, 4*(6+4N) B per agent-step): lanes stage
-// (x, y, type, active) as float4 per agent in LDS; the wave's rows form ONE contiguous region of
-// the [E][N][L] output, written with full-width global_store_dwordx4 whose two 8-byte halves come
-// from LDS addresses pre-computed once per workgroup (a u16 table in LDS), so the per-step cost of
-// a 1 KiB store is one ds_read_b32 + two ds_read_b64.
+//   4. with M = mask of earlier ranks that DID move, rank k moves iff ((M & P) | (~M & C)) == 0.
+//      M is a wave ballot; F(M) has a unique fixed point reached in <= N rounds (bit k of F
+//      depends on bits < k only); the loop is skipped when no lane depends on an earlier rank and
+//      exits as soon as two consecutive ballots agree.
 //
 // Everything is integer / index work; the only floating-point operation on the path is ONE f64
 // multiply per reward (compiled with -ffp-contract=off).  No MFMA on purpose.
@@ -46,6 +55,12 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Workgroup barrier that orders LDS traffic ONLY: __syncthreads() would also wait for vmcnt(0),
+// i.e. drain the writer wave's global stores at every step.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <int GLOG> struct GroupMask { using type = uint32_t; };
@@ -83,7 +98,23 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return v;
 }
 
-// per-wave LDS tile
+// Keep a wave-uniform value in VGPRs on purpose: the step loop needs ~60 scalars (geometry,
+// pointers, reward constants) next to the ballot masks, which overflows the 102 SGPRs and makes
+// hipcc spill SGPRs through v_writelane/v_readlane inside the loop.  VGPRs are plentiful here
+// (one or two waves per SIMD), so loop-invariant values that are only used by vector
+// instructions anyway are pinned there.
+template <typename T> __device__ __forceinline__ T in_vgpr(T v) {
+    if constexpr (sizeof(T) == 8) {
+        unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+        asm volatile("" : "+v"(u));
+        return __builtin_bit_cast(T, u);
+    } else {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
+}
+
+// per-tile LDS (observe kernel: WaveLds only)
 struct WaveLds {
     float4 slot[64];   // (x, y, type, active) of the agent on each lane, as floats
     float cst[8];      // (door_centre, division_y) (door_left, door_right) (-1,-1) pad
@@ -92,8 +123,14 @@ struct WaveLds {
 static_assert(sizeof(WaveLds) == 1024 + 32 + 256, "WaveLds layout");
 static constexpr uint32_t kCstOff = 1024;  // byte offset of cst[] from slot[]
 
-// u16 table entry for float2 unit `w` of a wave's observation region: byte offset (from the wave's
-// WaveLds) of the 8 bytes to copy there.  Row layout (observations.py:64-92):
+struct TileLds {
+    WaveLds w;
+    uint4 stage[2][64];  // sim -> writer hand-off, double buffered: {cell lo, cell hi, af, ef}
+};
+static_assert(sizeof(TileLds) == 1312 + 2048, "TileLds layout");
+
+// u16 table entry for float2 unit `w` of a tile's observation region: byte offset (from the
+// tile's WaveLds) of the 8 bytes to copy there.  Row layout (observations.py:64-92):
 //   unit 0 = (x_i, y_i); unit 1 = (door_centre, division_y); unit 2 = (door_left, door_right);
 //   unit 3+2j = (x_j, y_j), unit 4+2j = (type_j, active_j), or (-1,-1) for j == i.
 template <int GLOG>
@@ -127,54 +164,28 @@ __device__ __forceinline__ void init_wave_consts(WaveLds* wl, const KParams& p, 
     }
 }
 
-// copy the wave's observation region out of LDS: `units` float2 units starting at `dst`
+// copy a tile's observation region out of LDS, table-driven: vector units [first, n) of `dst`
 template <bool PAIR>
-__device__ __forceinline__ void emit_obs(const WaveLds* wl, const uint16_t* table, float* dst,
-                                         int units, int lane) {
+__device__ __forceinline__ void emit_obs(const WaveLds* wl, const uint16_t* table, char* dst,
+                                         int first, int n, int lane) {
     const char* sbase = reinterpret_cast<const char*>(wl);
-    if constexpr (PAIR) {
-        // N even: region start and length are multiples of 16 bytes
-        const uint32_t* t32 = reinterpret_cast<const uint32_t*>(table);
-        v4f* d4 = reinterpret_cast<v4f*>(dst);
-        const int n4 = units >> 1;
-        for (int q = lane; q < n4; q += 64) {
-            uint32_t t = t32[q];
+    for (int q = first + lane; q < n; q += 64) {
+        if constexpr (PAIR) {
+            // N even: region start and length are multiples of 16 bytes
+            const uint32_t t = reinterpret_cast<const uint32_t*>(table)[q];
             float2 a = *reinterpret_cast<const float2*>(sbase + (t & 0xFFFFu));
             float2 b = *reinterpret_cast<const float2*>(sbase + (t >> 16));
             v4f v = {a.x, a.y, b.x, b.y};
-            __builtin_nontemporal_store(v, &d4[q]);
-        }
-    } else {
-        float2* d2 = reinterpret_cast<float2*>(dst);
-        for (int w = lane; w < units; w += 64) {
-            float2 a = *reinterpret_cast<const float2*>(sbase + table[w]);
-            d2[w] = a;
+            __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst + (size_t)q * 16));
+        } else {
+            *reinterpret_cast<float2*>(dst + (size_t)q * 8) =
+                *reinterpret_cast<const float2*>(sbase + table[q]);
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// the fused rollout / step kernel
-// ---------------------------------------------------------------------------------------------
-
-// Keep a wave-uniform value in VGPRs on purpose: the step loop needs ~60 scalars (geometry,
-// pointers, reward constants) next to the ballot masks, which overflows the 102 SGPRs and makes
-// hipcc spill SGPRs through v_writelane/v_readlane inside the loop.  VGPRs are plentiful here
-// (one or two waves per SIMD), so the loop-invariant values that are only used by vector
-// instructions anyway are pinned there.
-template <typename T> __device__ __forceinline__ T in_vgpr(T v) {
-    if constexpr (sizeof(T) == 8) {
-        unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-        asm volatile("" : "+v"(u));
-        return __builtin_bit_cast(T, u);
-    } else {
-        asm volatile("" : "+v"(v));
-        return v;
-    }
-}
-
-// Diagnostic build only (-DCCX_STAMPS): s_memtime stamps around the segments of one step; wave 0
-// adds its per-segment cycle sums to counters[8..15].  Never compiled into libccx.so.
+// Diagnostic build only (-DCCX_STAMPS): s_memtime stamps around the segments of one step; the
+// waves of block 0 add their per-segment cycle sums to counters[8..15].  Never in libccx.so.
 #ifdef CCX_STAMPS
 #define CCX_STAMP(slot)                                                                     \
     do {                                                                                    \
@@ -185,60 +196,217 @@ template <typename T> __device__ __forceinline__ T in_vgpr(T v) {
         stamp_sum[slot] += t_ - t_prev;                                                     \
         t_prev = t_;                                                                        \
     } while (0)
+#define CCX_STAMP_DECL                                                                      \
+    unsigned long long stamp_sum[4] = {0, 0, 0, 0}, t_prev = 0;                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory")
+#define CCX_STAMP_FLUSH(ctr, base)                                                          \
+    if ((ctr) && blockIdx.x == 0 && lane == 0)                                              \
+        for (int q_ = 0; q_ < 4; ++q_) atomicAdd(&(ctr)[8 + (base) + q_], stamp_sum[q_])
 #else
 #define CCX_STAMP(slot) do { } while (0)
+#define CCX_STAMP_DECL do { } while (0)
+#define CCX_STAMP_FLUSH(ctr, base) do { } while (0)
 #endif
 
-constexpr int kActBatch = 16;  // env-steps of actions fetched per global-load burst
+constexpr int kActBatch = 16;      // env-steps of actions fetched per global-load burst
+constexpr int kFastObsIters = 10;  // observation store iterations whose LDS addresses live in VGPRs
+constexpr int kObsBatch = 5;       // LDS reads issued back to back before their stores
 
-template <int GLOG, bool PAIR>
-__global__ void __launch_bounds__(256)
-rollout_kernel(const KParams p, const KState st, const uint8_t* __restrict__ actions,
-               const uint8_t* __restrict__ order, const int K, const int auto_reset,
-               const uint8_t* __restrict__ pool, const KOut out, unsigned long long* counters) {
+// ---- per-cell geometry table ------------------------------------------------------------------
+// Everything the step needs to know about a grid cell is precomputed once per handle on the host
+// (ccx_api.hip: build_cell_table) for the padded grid x in [-1, W+1], y in [-1, H+1]
+// (cell = (y+1)*(W+3) + (x+1)), copied to LDS at kernel start and looked up ONCE per agent-step
+// for the proposed cell:
+//   lo: bit0 VALID  in-grid and not a wall          (collectivecrossing.py:509-534)
+//       bit4 IN_TRAM_AREA (:551-554)  bit5 AT_DOOR (:556-563)       -- same bits as CCX_AF_*
+//       bit8  boarding: on destination row (:663-683)   bits 9-10  boarding reward class
+//       bit12 exiting:  on destination row              bits 13-14 exiting reward class
+//       byte2 = x, byte3 = y  (0 for border cells)
+//   hi: int16 signed distance term of the boarding reward | int16 of the exiting reward << 16
+// reward class (rewards.py:44-182): 0 = (double)sd * distance_penalty_factor, 1/2/3 = constants
+// rA/rB/rC chosen per reward mode.
+//
+// sim -> writer hand-off (uint4 per lane and step): x = cell lo, y = cell hi, z = the CCX_AF_*
+// byte of the agent, w = the CCX_EF_* byte of its env.
+
+// ---------------------------------------------------------------------------------------------
+// the fused rollout / step kernel.  OUT = trajectory outputs requested: the workgroup then has
+// 2 * waves_per_block wavefronts, wave t < waves_per_block simulating tile t and wave
+// t + waves_per_block writing its outputs.  OUT = false: sim waves only, counters only.
+// ---------------------------------------------------------------------------------------------
+template <int GLOG, bool PAIR, bool OUT>
+__global__ void __launch_bounds__(512)
+rollout_kernel(const KParams p, const KState st, const unsigned long long* __restrict__ cell_info,
+               const uint8_t* __restrict__ actions, const uint8_t* __restrict__ order, const int K,
+               const int auto_reset, const uint8_t* __restrict__ pool, const KOut out,
+               unsigned long long* counters) {
     using mask_t = typename GroupMask<GLOG>::type;
     constexpr int G = 1 << GLOG;
     extern __shared__ __align__(16) unsigned char smem[];
 
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    const int wave = blockIdx.x * p.waves_per_block + wib;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
+    const bool is_writer = OUT && (wib >= p.waves_per_block);
+    const int tile_in_block = is_writer ? wib - p.waves_per_block : wib;
+    const int tile = blockIdx.x * p.waves_per_block + tile_in_block;
     const int g = lane >> GLOG;
     const int i = lane & (G - 1);
     const int gbase = g << GLOG;
-    const int env0 = wave * p.EW;                 // first env of this wave
+    const int env0 = tile * p.EW;                 // first env of this tile
     const int env = env0 + g;
     const bool valid_env = (g < p.EW) && (env < p.E);
     const bool valid = valid_env && (i < p.N);
+    const uint32_t validbit = valid ? 1u : 0u;
     const int N = p.N;
     const int L = 6 + 4 * N;
     const size_t EN = (size_t)p.E * N;
     const size_t idx = (size_t)env * N + i;
     const bool boarding = i < p.Nb;
-    const int dest_y = boarding ? p.bdy : p.edy;
-    const mask_t full = full_mask<GLOG>();
-    const mask_t lo = low_mask<mask_t>(i);
-    const mask_t later = ~lo & ~(mask_t(1) << i);
+    const uint32_t tsh = boarding ? 8u : 12u;     // type-specific nibble of the cell word
+    const uint32_t tsh2 = boarding ? 0u : 16u;    // type-specific half of the distance word
+    const int Wp = p.W + 3;
 
-    // LDS carve-up: [WaveLds x waves_per_block][u16 table]
-    WaveLds* wl = reinterpret_cast<WaveLds*>(smem) + wib;
-    uint16_t* table = reinterpret_cast<uint16_t*>(smem + sizeof(WaveLds) * p.waves_per_block);
-    const bool want_obs = out.obs != nullptr;
+    // LDS carve-up: [cell table u64 x cells][TileLds x waves_per_block][u16 obs table]
+    const uint32_t cells = (uint32_t)(Wp * (p.H + 3));
+    const uint32_t cell_bytes = (cells * 8u + 15u) & ~15u;
+    unsigned long long* cinfo = reinterpret_cast<unsigned long long*>(smem);
+    TileLds* tl = reinterpret_cast<TileLds*>(smem + cell_bytes) + tile_in_block;
+    WaveLds* wl = &tl->w;
+    uint16_t* table = reinterpret_cast<uint16_t*>(smem + cell_bytes + sizeof(TileLds) * p.waves_per_block);
+    const bool want_obs = OUT && out.obs != nullptr;
+    for (uint32_t t = threadIdx.x; t < cells; t += blockDim.x) cinfo[t] = cell_info[t];
     if (want_obs) build_obs_table<GLOG>(table, p);
-    init_wave_consts(wl, p, lane);
-    __syncthreads();  // the only workgroup barrier: table is read-only from here on
+    if (!is_writer) init_wave_consts(wl, p, lane);
+    __syncthreads();  // tables are read-only from here on
 
     int envs_here = p.E - env0;
     envs_here = envs_here < 0 ? 0 : (envs_here > p.EW ? p.EW : envs_here);
     const int units = envs_here * N * (3 + 2 * N);
+    const int n4 = PAIR ? (units >> 1) : units;     // vector units (16 B or 8 B) of the obs region
+
+    // =========================================================================================
+    // WRITER wave: reward, flag bytes, observation rows of every step (reference phases :214-261)
+    // =========================================================================================
+    if constexpr (OUT) {
+        if (is_writer) {
+            const float type_f = boarding ? 0.0f : 1.0f;  // observations.py:85
+            // reward constants (rewards.py:44-182): class 1/2/3 -> rA/rB/rC, class 0 -> sd * rF
+            const int rmode = p.reward_mode;
+            const double rA = in_vgpr(rmode == CCX_K_REWARD_BINARY ? p.r_nogoal
+                                      : rmode == CCX_K_REWARD_CONSTANT_NEGATIVE ? p.r_pen : p.r_dest);
+            const double rB = in_vgpr(p.r_door);
+            const double rC = in_vgpr(p.r_area);
+            const double rF = in_vgpr(p.r_f);
+            // wave-uniform base pointers advanced per step on the scalar unit + per-lane 32-bit
+            // byte offsets that never change
+            const uint32_t rew_off = (uint32_t)idx * 8u, af_off = (uint32_t)idx, ef_off = (uint32_t)env;
+            char* rew_s = reinterpret_cast<char*>(out.reward);
+            char* af_s = reinterpret_cast<char*>(out.agent_flags);
+            char* ef_s = reinterpret_cast<char*>(out.env_flags);
+            char* obs_s = reinterpret_cast<char*>(out.obs) + (size_t)env0 * N * L * 4;
+            const size_t obs_stride = EN * (size_t)L * 4;
+            // LDS source addresses of this lane's first kFastObsIters observation stores
+            uint32_t oa0[kFastObsIters], oa1[kFastObsIters];
+#pragma unroll
+            for (int it = 0; it < kFastObsIters; ++it) {
+                const int q = lane + 64 * it;
+                oa0[it] = oa1[it] = kCstOff + 16u;
+                if (want_obs && q < n4) {
+                    if constexpr (PAIR) {
+                        const uint32_t t = reinterpret_cast<const uint32_t*>(table)[q];
+                        oa0[it] = t & 0xFFFFu;
+                        oa1[it] = t >> 16;
+                    } else {
+                        oa0[it] = table[q];
+                    }
+                }
+            }
+            const char* sbase = reinterpret_cast<const char*>(wl);
+            CCX_STAMP_DECL;
+
+            for (int s = 0; s < K; ++s) {
+                lds_barrier();                       // the sim wave has staged step s
+                const uint4 e = tl->stage[s & 1][lane];
+                CCX_STAMP(0);                        // wait for the sim wave
+                const uint32_t ilo = e.x, ihi = e.y, af = e.z;
+                if (want_obs) {
+                    // (x, y) are bytes 2 and 3 of the cell word: v_cvt_f32_ubyte2 / ubyte3
+                    wl->slot[lane] = make_float4((float)((ilo >> 16) & 0xFFu), (float)(ilo >> 24), type_f,
+                                                 (float)((af >> 6) & 1u));
+                }
+                // rewards.py:44-182.  Distances are integers and the reference negates the
+                // INTEGER before the one f64 multiply, so d == 0 gives +0.0 (never -0.0).
+                const uint32_t cls = (ilo >> (tsh + 1u)) & 3u;
+                const int sd = (int)(int16_t)(uint16_t)(ihi >> tsh2);
+                double r = (double)sd * rF;
+                r = (cls == 1u) ? rA : r;
+                r = (cls == 2u) ? rB : r;
+                r = (cls == 3u) ? rC : r;
+                r = (af & 0x04u) ? r : 0.0;          // rewards.py:64: None unless live
+                if (valid) {
+                    if (rew_s) *reinterpret_cast<double*>(rew_s + rew_off) = r;
+                    if (af_s) *reinterpret_cast<uint8_t*>(af_s + af_off) = (uint8_t)af;
+                    if (ef_s && i == 0) *reinterpret_cast<uint8_t*>(ef_s + ef_off) = (uint8_t)e.w;
+                }
+                if (rew_s) rew_s += EN * 8;
+                if (af_s) af_s += EN;
+                if (ef_s) ef_s += p.E;
+                CCX_STAMP(1);                        // reward + flag bytes
+                if (want_obs) {
+                    wave_lds_sync();
+                    // all LDS reads of a batch first (idle lanes read the constant slot), so the
+                    // wave pays one LDS latency per batch, then the stores
+#pragma unroll
+                    for (int it0 = 0; it0 < kFastObsIters; it0 += kObsBatch) {
+                        if (64 * it0 < n4) {
+                            float2 va[kObsBatch], vb[kObsBatch];
+#pragma unroll
+                            for (int j = 0; j < kObsBatch; ++j) {
+                                va[j] = *reinterpret_cast<const float2*>(sbase + oa0[it0 + j]);
+                                if constexpr (PAIR)
+                                    vb[j] = *reinterpret_cast<const float2*>(sbase + oa1[it0 + j]);
+                            }
+#pragma unroll
+                            for (int j = 0; j < kObsBatch; ++j) {
+                                const int q = lane + 64 * (it0 + j);
+                                if (q < n4) {
+                                    if constexpr (PAIR) {
+                                        v4f v = {va[j].x, va[j].y, vb[j].x, vb[j].y};
+                                        __builtin_nontemporal_store(
+                                            v, reinterpret_cast<v4f*>(obs_s + (uint32_t)q * 16u));
+                                    } else {
+                                        *reinterpret_cast<float2*>(obs_s + (uint32_t)q * 8u) = va[j];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (n4 > 64 * kFastObsIters)
+                        emit_obs<PAIR>(wl, table, obs_s, 64 * kFastObsIters, n4, lane);
+                    obs_s += obs_stride;
+                    wave_lds_sync();
+                }
+                CCX_STAMP(2);                        // observation gather + stores
+            }
+            CCX_STAMP_FLUSH(counters, 4);
+            return;
+        }
+    }
+
+    // =========================================================================================
+    // SIM wave: the state transition (reference phases :188-212, :219-241 and the auto-reset)
+    // =========================================================================================
+    const mask_t full = full_mask<GLOG>();
+    const mask_t lo_m = low_mask<mask_t>(i);
+    const mask_t later_m = ~lo_m & ~(mask_t(1) << i);
 
     // ---- state -> registers ------------------------------------------------------------------
-    int x = 0, y = 0, stepc = 0, episode = 0;
-    bool active = false, term = false, trunc = false;
+    int c = Wp + 1;               // cell index of (0,0)
+    int stepc = 0, episode = 0;
+    uint32_t act = 0, term = 0, trunc = 0;   // 0/1
     if (valid) {
-        x = st.x[idx];
-        y = st.y[idx];
-        active = st.active[idx] != 0;
+        c = (st.y[idx] + 1) * Wp + st.x[idx] + 1;
+        act = st.active[idx] != 0;
         term = st.terminated[idx] != 0;
         trunc = st.truncated[idx] != 0;
     }
@@ -246,6 +414,8 @@ rollout_kernel(const KParams p, const KState st, const uint8_t* __restrict__ act
         stepc = st.step_count[env];
         episode = st.episode[env];
     }
+    unsigned long long ci = cinfo[c];
+    uint32_t ilo = (uint32_t)ci, ihi = (uint32_t)(ci >> 32);
     // final write-back addresses, parked in VGPRs for the duration of the loop
     int32_t* const fx = in_vgpr(st.x + idx);
     int32_t* const fy = in_vgpr(st.y + idx);
@@ -255,52 +425,40 @@ rollout_kernel(const KParams p, const KState st, const uint8_t* __restrict__ act
     int32_t* const fstep = in_vgpr(st.step_count + env);
     int32_t* const fepi = in_vgpr(st.episode + env);
     unsigned long long* const ctr = in_vgpr(counters);
+    const uint32_t term_all = (p.term_mode == CCX_K_TERM_ALL) ? 1u : 0u;
 
-    // reward constants, selected once (rewards.py:44-182):  r = c1 ? rA : c2 ? rB : c3 ? rC : d*rF
-    const int rmode = p.reward_mode;
-    const double rA = in_vgpr(rmode == CCX_K_REWARD_BINARY ? p.r_nogoal
-                              : rmode == CCX_K_REWARD_CONSTANT_NEGATIVE ? p.r_pen : p.r_dest);
-    const double rB = in_vgpr(p.r_door);
-    const double rC = in_vgpr(p.r_area);
-    const double rF = in_vgpr(p.r_f);
+    // move deltas in the padded grid, one signed byte per action 0..4 (actions.py:18-24)
+    const unsigned long long lut = (unsigned long long)(uint8_t)1 | ((unsigned long long)(uint8_t)Wp << 8) |
+                                   ((unsigned long long)(uint8_t)(-1) << 16) |
+                                   ((unsigned long long)(uint8_t)(-Wp) << 24);
 
     // reset-pool cursor of this env: entry (global_env + episode*total) mod P, advanced by
     // total mod P per episode; the NEXT placement is prefetched right after every reset and only
     // decoded when it is consumed (so no wait sits behind the load).
     uint32_t pool_idx = 0, pnext = 0;
-    int px = 0, py = 0;
-    bool pnext_pending = false;   // pnext holds a load that has not been decoded into px/py yet
+    int pcell = Wp + 1;
+    bool pnext_pending = false;   // pnext holds a load that has not been decoded into pcell yet
     const bool use_pool = auto_reset && pool != nullptr && p.pool_size > 0;
     const uint32_t pool_size = (uint32_t)p.pool_size, pool_stride = (uint32_t)p.pool_stride;
-    const uint8_t* const pool_v = pool;   // stays a global-address-space pointer (SGPR pair)
     if (use_pool && valid) {
         unsigned long long P = (unsigned long long)p.pool_size;
         unsigned long long gi = (unsigned long long)(p.env_offset + env) % P;
         unsigned long long ep = (unsigned long long)(episode + 1) % P;
         pool_idx = (uint32_t)((gi + ep * (unsigned long long)p.pool_stride) % P);
-        pnext = *reinterpret_cast<const uint16_t*>(pool_v + ((size_t)pool_idx * N + i) * 2);
+        pnext = *reinterpret_cast<const uint16_t*>(pool + ((size_t)pool_idx * N + i) * 2);
         pnext_pending = true;
     }
 
-    // per-lane output cursors, advanced by one step's stride per iteration
-    double* rew_p = out.reward ? out.reward + idx : nullptr;
-    uint8_t* af_p = out.agent_flags ? out.agent_flags + idx : nullptr;
-    uint8_t* ef_p = out.env_flags ? out.env_flags + env : nullptr;
-    float* obs_p = want_obs ? out.obs + (size_t)env0 * N * L : nullptr;
-    const size_t obs_stride = EN * (size_t)L;
     const uint8_t* act_p = actions + idx;
-    const uint8_t* ord_p = order ? order + idx : nullptr;
+    const bool has_order = order != nullptr;   // wave-uniform
+    const uint8_t* ord_p = order + idx;
 
     uint32_t c_moves = 0, c_arrivals = 0, c_live = 0, c_episodes = 0;
-#ifdef CCX_STAMPS
-    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
-#endif
+    CCX_STAMP_DECL;
 
-    // ---- actions: bursts of kActBatch steps, 4 bits per step in a u64 --------------------------
-    // One s_waitcnt vmcnt per burst instead of one per step (vmcnt also counts the stores).
-    // Loads are unconditional (steps past K re-read the last valid step) and addressed from a
-    // VGPR stride, so the burst is straight-line code with no scalar address table.
+    // ---- actions: bursts of kActBatch steps, 4 bits per step ----------------------------------
+    // One s_waitcnt vmcnt per burst instead of one per step.  Loads are unconditional (steps past
+    // K re-read the last valid step) and addressed from a VGPR stride: straight-line code.
     uint32_t araw[kActBatch];
     const size_t EN_v = in_vgpr(EN);
     auto fetch_actions = [&](int s_first) {
@@ -308,36 +466,42 @@ rollout_kernel(const KParams p, const KState st, const uint8_t* __restrict__ act
 #pragma unroll
         for (int d = 0; d < kActBatch; ++d) {
             const int dd = d < last ? d : last;
-            araw[d] = valid ? (uint32_t)act_p[(size_t)dd * EN_v] : CCX_K_ABSENT;
+            araw[d] = valid ? (uint32_t)act_p[(size_t)dd * EN_v] : 4u;
         }
         act_p += (size_t)kActBatch * EN_v;
     };
     fetch_actions(0);
 
+    int s = 0;
     for (int s0 = 0; s0 < K; s0 += kActBatch) {
-        // the burst issued one batch ago is consumed here: ONE vmcnt wait per kActBatch steps
-        unsigned long long apack = 0;
+        // the burst issued one batch ago is consumed here: ONE vmcnt wait per kActBatch steps.
+        // Actions are clamped to 0..4 (4 = wait; 255 = absent and anything else: no move).
+        uint32_t apk[2] = {0, 0};
 #pragma unroll
-        for (int d = 0; d < kActBatch; ++d)
-            apack |= (unsigned long long)(araw[d] & 0xFu) << (4 * d);   // 255 -> 15: no move
-        apack = in_vgpr(apack);
+        for (int d = 0; d < kActBatch; ++d) {
+            const uint32_t a4 = araw[d] < 4u ? araw[d] : 4u;
+            apk[d >> 3] |= a4 << (4 * (d & 7));
+        }
+        apk[0] = in_vgpr(apk[0]);
+        apk[1] = in_vgpr(apk[1]);
         if (pnext_pending) {   // decode behind the wait that just happened: costs nothing
-            px = (int)(pnext & 0xFFu);
-            py = (int)(pnext >> 8);
+            pcell = (int)(pnext >> 8) * Wp + (int)(pnext & 0xFFu) + Wp + 1;
             pnext_pending = false;
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the next burst BEHIND the wait above
         if (s0 + kActBatch < K) fetch_actions(s0 + kActBatch);
         __builtin_amdgcn_sched_barrier(0);
         const int dmax = (K - s0) < kActBatch ? (K - s0) : kActBatch;
-        CCX_STAMP(0);   // burst wait + pack + next burst issue
 
-        for (int d = 0; d < dmax; ++d) {
-            const uint32_t a = (uint32_t)(apack >> (4 * d)) & 0xFu;
+        uint32_t acur = apk[0];
+        for (int d = 0; d < dmax; ++d, ++s) {
+            if (d == 8) acur = apk[1];
+            const uint32_t a = acur & 0xFu;
+            acur >>= 4;
 
             // ---- move rank of this agent (dict order of action_dict, collectivecrossing.py:197)
             int rank = i;
-            if (ord_p != nullptr) {
+            if (has_order) {
                 uint32_t ok_ = valid ? (uint32_t)*ord_p : (uint32_t)i;  // agent moved i-th
                 ord_p += EN;
                 wl->xch[gbase + (ok_ & (G - 1))] = (uint32_t)i;
@@ -347,165 +511,141 @@ rollout_kernel(const KParams p, const KState st, const uint8_t* __restrict__ act
             }
 
             stepc += 1;  // collectivecrossing.py:188
-            CCX_STAMP(7);   // loop overhead / order path
 
-            // ---- 1. proposal (collectivecrossing.py:371-376, 509-534; 565-588 adds nothing)
-            const int dx = (a == 0u) - (a == 2u);
-            const int dy = (a == 1u) - (a == 3u);
-            const int nx = x + dx, ny = y + dy;
-            bool ok = valid && active && (a < 4u);
-            ok = ok && ((unsigned)nx <= (unsigned)p.W) && ((unsigned)ny <= (unsigned)p.H);
-            ok = ok && !(ny == p.div && !(p.dl < nx && nx < p.dr));
-            ok = ok && !(ny >= p.div && !(p.tl < nx && nx < p.tr));
-            const uint32_t curkey = (valid && active) ? (uint32_t)(x | (y << 8)) : 0x8000u;
-            const uint32_t propkey = ok ? (uint32_t)(nx | (ny << 8)) : 0xFFFFu;
+            // ---- 1. proposal: target cell + ONE table lookup (collectivecrossing.py:371-376,
+            //         509-534; :565-588 adds nothing to :509-534)
+            const int delta = (int)(int8_t)(uint8_t)(lut >> (a * 8u));
+            const int np = c + delta;
+            const unsigned long long pci = cinfo[np];
+            const uint32_t plo = (uint32_t)pci, phi = (uint32_t)(pci >> 32);
+            const uint32_t ok = act & (a != 4u) & plo;          // bit0 of plo = VALID
+            const uint32_t curkey = act ? (uint32_t)c : 0x8000u;
+            const uint32_t propkey = (ok & 1u) ? (uint32_t)np : 0xFFFFu;
             wl->xch[gbase + rank] = curkey | (propkey << 16);
             wave_lds_sync();
 
             // ---- 2. this lane now plays move-rank i of its group.  Entries of unused lanes hold
             //         cur 0x8000 / prop 0xFFFF and can never match a real proposal.
             const uint32_t myprop = wl->xch[lane] >> 16;
-            mask_t call = 0, pall = 0;
+            mask_t call, pall;
+            if constexpr (GLOG <= 4) {
+                // both 16-bit compares of an entry in 3 VALU ops: xor with (prop,prop), clamp
+                // each half to 0/1 ("differs"), shift into a packed accumulator
+                const uint32_t mp2 = myprop | (myprop << 16);
+                uint32_t acc = 0;
 #pragma unroll
-            for (int k2 = 0; k2 < G; ++k2) {
-                const uint32_t v = wl->xch[gbase + k2];
-                call |= (mask_t)((v & 0xFFFFu) == myprop) << k2;
-                pall |= (mask_t)((v >> 16) == myprop) << k2;
+                for (int k2 = G - 1; k2 >= 0; --k2) {
+                    const uint32_t t = wl->xch[gbase + k2] ^ mp2;
+                    uint32_t ne;   // per 16-bit half: 1 if it differs, 0 if equal
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(ne) : "v"(t), "v"(0x00010001u));
+                    acc = (acc << 1) | ne;
+                }
+                const uint32_t eq = ~acc;
+                call = (mask_t)(eq & 0xFFFFu) & full;
+                pall = (mask_t)(eq >> 16) & full;
+            } else {
+                call = 0;
+                pall = 0;
+#pragma unroll
+                for (int k2 = 0; k2 < G; ++k2) {
+                    const uint32_t v = wl->xch[gbase + k2];
+                    call |= (mask_t)((v & 0xFFFFu) == myprop) << k2;
+                    pall |= (mask_t)((v >> 16) == myprop) << k2;
+                }
             }
-            CCX_STAMP(1);   // proposal + LDS exchange + pair masks
-            const mask_t Cm = call & lo, Pm = pall & lo;
-            const bool okr = (myprop != 0xFFFFu) && ((call & later) == 0);  // later ranks: old cells
+            CCX_STAMP(0);   // loop top + proposal + LDS exchange + pair masks
+            const mask_t Cm = call & lo_m, Pm = pall & lo_m;
+            const bool okr = (myprop != 0xFFFFu) && ((call & later_m) == 0);  // later ranks: old cells
 
-            // ---- 3. ballot fixed point over "who moved"
-            uint64_t b = __ballot(okr && (Cm == 0));
-            for (int it = 1; it < N; ++it) {
-                const mask_t M = group_bits<GLOG>(b, lane);
-                const uint64_t b2 = __ballot(okr && (((M & Pm) | (~M & Cm)) == 0));
-                if (b2 == b) break;
-                b = b2;
+            // ---- 3. ballot fixed point over "who moved": F(M) is constant for lanes without any
+            //         earlier-rank dependency, so the loop only runs when some lane has one.
+            uint64_t b = __builtin_amdgcn_ballot_w64(okr && (Cm == 0));
+            if (__builtin_amdgcn_ballot_w64(okr && ((Cm | Pm) != 0)) != 0) {
+                for (int it = 1; it < N; ++it) {
+                    const mask_t M = group_bits<GLOG>(b, lane);
+                    const uint64_t b2 = __builtin_amdgcn_ballot_w64(okr && (((M & Pm) | (~M & Cm)) == 0));
+                    if (b2 == b) break;
+                    b = b2;
+                }
             }
             wave_lds_sync();  // xch is rewritten next step
-            const bool moved = (group_bits<GLOG>(b, lane) >> rank) & 1;
+            const uint32_t moved = (uint32_t)(group_bits<GLOG>(b, lane) >> rank) & 1u;
             if (moved) {  // collectivecrossing.py:408
-                x = nx;
-                y = ny;
+                c = np;
+                ilo = plo;
+                ihi = phi;
             }
             c_moves += moved;
-            CCX_STAMP(2);   // ballot fixed point + position update
+            CCX_STAMP(1);   // ballot fixed point + position update
 
-            // ---- 4. tail: deactivate, reward, terminated, truncated, flags (:210-241)
-            const bool at_dest = (y == dest_y);                       // :663-683
-            const bool arrive = valid && active && at_dest;           // :210-212
-            active = active && !arrive;
+            // ---- 4. tail in 0/1 integer arithmetic: deactivate, terminated, truncated, flags
+            //         (collectivecrossing.py:210-259)
+            const uint32_t dest = (ilo >> tsh) & 1u;                 // :663-683
+            const uint32_t arrive = act & dest;                      // :210-212 (act is 0 off-grid)
+            act &= ~dest;
+            const uint32_t live = validbit & ~(term | trunc);        // rewards.py:64, truncateds.py:56
             c_arrivals += arrive;
-            const bool live = valid && !(term || trunc);              // rewards.py:64, truncateds.py:56
             c_live += live;
-            const bool in_area = (y >= p.div) && (p.tl <= x) && (x <= p.tr);         // :551-554
-            const bool at_door = (y == p.div) && (x == p.dl - 1 || x == p.dr + 1);   // :556-563
-
-            // rewards.py:44-182.  Distances are integers and the reference negates the INTEGER
-            // before the one f64 multiply, so d == 0 gives +0.0 (never -0.0).
-            bool c1 = true, c2 = false, c3 = false;
-            int sd = 0;
-            if (rmode == CCX_K_REWARD_DEFAULT) {
-                const int adx = x > p.dc ? x - p.dc : p.dc - x;
-                c1 = at_dest;
-                c2 = boarding && at_door;
-                c3 = boarding ? in_area : !in_area;
-                sd = boarding ? -(adx + (p.div - y)) : (adx + (y - p.div));
-            } else if (rmode == CCX_K_REWARD_SIMPLE_DISTANCE) {
-                c1 = false;
-                sd = -(y > dest_y ? y - dest_y : dest_y - y);
-            }
-            double r = c1 ? rA : c2 ? rB : c3 ? rC : (double)sd * rF;
-            if (!live) r = 0.0;
-
-            bool term_out = at_dest;                                   // terminateds.py:66-82
-            const mask_t dest_bits = group_bits<GLOG>(__ballot(at_dest || !valid), lane);
-            if (p.term_mode == CCX_K_TERM_ALL) term_out = (dest_bits == full);   // terminateds.py:40-60
-            const bool trunc_out = live && (stepc >= p.max_steps);     // truncateds.py:40-61
-            const bool done_now = (term_out && !term) || (trunc_out && !trunc);  // :229-241
-            term = term || term_out;
-            trunc = trunc || trunc_out;
-            const bool emit = done_now || !(term || trunc);            // :243, :763-767
-
-            const mask_t term_bits = (p.term_mode == CCX_K_TERM_ALL)
-                                         ? (term_out ? full : mask_t(0))
-                                         : dest_bits;
-            const bool all_term = (term_bits == full);                 // :256
-            const mask_t live_bits = group_bits<GLOG>(__ballot(live), lane);
-            const mask_t tr_bits = group_bits<GLOG>(__ballot(!live || trunc_out), lane);
-            const bool all_trunc = (live_bits != 0) && (tr_bits == full);  // :257
-            uint32_t ef = (all_term ? CCX_K_EF_ALL_TERM : 0u) | (all_trunc ? CCX_K_EF_ALL_TRUNC : 0u);
-
-            const uint32_t af = (term_out ? 0x01u : 0u) | (trunc_out ? 0x02u : 0u) |
-                                (live ? 0x04u : 0u) | (emit ? 0x08u : 0u) | (in_area ? 0x10u : 0u) |
-                                (at_door ? 0x20u : 0u) | (active ? 0x40u : 0u) | (at_dest ? 0x80u : 0u);
-
-            CCX_STAMP(3);   // tail: reward / flags / ballots
-            // ---- 5. outputs
-            if (valid) {
-                if (rew_p) {
-                    *rew_p = r;
-                    rew_p += EN;
-                }
-                if (af_p) {
-                    *af_p = (uint8_t)af;
-                    af_p += EN;
-                }
-            }
-            CCX_STAMP(4);   // reward + flag stores
-            if (want_obs) {
-                wl->slot[lane] = make_float4((float)x, (float)y, boarding ? 0.0f : 1.0f,
-                                             active ? 1.0f : 0.0f);
-                wave_lds_sync();
-                emit_obs<PAIR>(wl, table, obs_p, units, lane);
-                obs_p += obs_stride;
-                wave_lds_sync();
-            }
-
-            CCX_STAMP(5);   // observation gather + stores
-            // ---- 6. auto-reset from the pool (reset() :97-150 with host-computed placements)
+            const mask_t dest_bits =
+                group_bits<GLOG>(__builtin_amdgcn_ballot_w64((dest | (validbit ^ 1u)) != 0), lane);
+            const mask_t live_bits = group_bits<GLOG>(__builtin_amdgcn_ballot_w64(live != 0), lane);
+            const uint32_t all_dest = dest_bits == full;             // terminateds.py:40-60 and :256
+            const uint32_t term_out = term_all ? all_dest : dest;    // terminateds.py:40-82
+            const uint32_t ge = stepc >= p.max_steps;                // truncateds.py:40-61
+            const uint32_t trunc_out = live & ge;
+            const uint32_t done_now = (term_out & ~term) | (trunc_out & ~trunc);  // :229-241
+            term |= term_out;
+            trunc |= trunc_out;
+            const uint32_t emit = (done_now | ~(term | trunc)) & 1u; // :243, :763-767
+            // every live agent truncates at once, so __all__ = (any live) && ge  (:257)
+            uint32_t ef = all_dest | (((live_bits != 0) & ge) << 1);
+            const uint32_t af = term_out | (trunc_out << 1) | (live << 2) | (emit << 3) |
+                                (ilo & 0x30u) | (act << 6) | (dest << 7);
             const bool do_reset = use_pool && valid_env && (ef != 0u);
+            if (do_reset) ef |= CCX_K_EF_RESET;
+
+            // ---- 5. hand the step to the writer wave
+            if constexpr (OUT) {
+                tl->stage[s & 1][lane] = make_uint4(ilo, ihi, af, ef);
+                CCX_STAMP(2);   // tail
+                lds_barrier();
+                CCX_STAMP(3);   // wait for the writer wave (it may lag one step at most)
+            }
+
+            // ---- 6. auto-reset from the pool (reset() :97-150 with host-computed placements)
             if (do_reset) {
-                ef |= CCX_K_EF_RESET;
                 episode += 1;
                 stepc = 0;
                 c_episodes += (i == 0);
                 if (valid) {
                     if (pnext_pending) {   // second reset inside one action burst (rare): wait here
                         asm volatile("; rare: reset twice within one action burst");
-                        px = (int)(pnext & 0xFFu);
-                        py = (int)(pnext >> 8);
+                        pcell = (int)(pnext >> 8) * Wp + (int)(pnext & 0xFFu) + Wp + 1;
                     }
-                    x = px;
-                    y = py;
-                    active = true;
-                    term = false;
-                    trunc = false;
+                    c = pcell;
+                    const unsigned long long rci = cinfo[c];
+                    ilo = (uint32_t)rci;
+                    ihi = (uint32_t)(rci >> 32);
+                    act = 1;
+                    term = 0;
+                    trunc = 0;
                     pool_idx += pool_stride;
                     if (pool_idx >= pool_size) pool_idx -= pool_size;
-                    pnext = *reinterpret_cast<const uint16_t*>(pool_v + ((size_t)pool_idx * N + i) * 2);
+                    pnext = *reinterpret_cast<const uint16_t*>(pool + ((size_t)pool_idx * N + i) * 2);
                     pnext_pending = true;
                 }
             }
-            if (ef_p && valid_env && i == 0) *ef_p = (uint8_t)ef;
-            if (ef_p) ef_p += p.E;
-            CCX_STAMP(6);   // auto-reset + env flag store
         }
     }
-#ifdef CCX_STAMPS
-    if (ctr && wave == 0 && lane == 0)
-        for (int q = 0; q < 8; ++q) atomicAdd(&ctr[8 + q], stamp_sum[q]);
-#endif
+    CCX_STAMP_FLUSH(ctr, 0);
 
     // ---- registers -> state ------------------------------------------------------------------
     if (valid) {
-        *fx = x;
-        *fy = y;
-        *fact = active;
-        *fterm = term;
-        *ftrunc = trunc;
+        *fx = (int)((ilo >> 16) & 0xFFu);
+        *fy = (int)(ilo >> 24);
+        *fact = (uint8_t)act;
+        *fterm = (uint8_t)term;
+        *ftrunc = (uint8_t)trunc;
     }
     if (valid_env && i == 0) {
         *fstep = stepc;
@@ -555,7 +695,9 @@ observe_kernel(const KParams p, const KState st, float* __restrict__ obs) {
     __syncthreads();
     int envs_here = p.E - env0;
     envs_here = envs_here < 0 ? 0 : (envs_here > p.EW ? p.EW : envs_here);
-    emit_obs<PAIR>(wl, table, obs + (size_t)env0 * N * L, envs_here * N * (3 + 2 * N), lane);
+    const int units = envs_here * N * (3 + 2 * N);
+    emit_obs<PAIR>(wl, table, reinterpret_cast<char*>(obs + (size_t)env0 * N * L), 0,
+                   PAIR ? (units >> 1) : units, lane);
 }
 
 // (re)start masked envs from their pool entry (reset() :97-150, placements precomputed on host)
@@ -583,20 +725,40 @@ __global__ void reset_from_pool_kernel(const KParams p, const KState st,
 // ---------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------
+template <int GLOG, bool PAIR, bool OUT>
+static hipError_t launch_rollout_v(const LaunchShape& ls, hipStream_t stream, const KParams& p,
+                                   const KState& st, const unsigned long long* cell_info,
+                                   const uint8_t* actions, const uint8_t* order, int K,
+                                   int auto_reset, const uint8_t* pool, const KOut& out,
+                                   unsigned long long* counters) {
+    if (ls.lds_bytes > 60 * 1024) {
+        // grids up to 100x100 need more than the default 64 KiB of dynamic LDS (160 KiB per CU)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<GLOG, PAIR, OUT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid(ls.num_blocks), block(64 * ls.waves_per_block * (OUT ? 2 : 1));
+    hipLaunchKernelGGL((rollout_kernel<GLOG, PAIR, OUT>), grid, block, ls.lds_bytes, stream, p, st,
+                       cell_info, actions, order, K, auto_reset, pool, out, counters);
+    return hipGetLastError();
+}
+
 template <int GLOG>
 static hipError_t launch_rollout_g(const LaunchShape& ls, hipStream_t stream, const KParams& p,
-                                   const KState& st, const uint8_t* actions, const uint8_t* order,
-                                   int K, int auto_reset, const uint8_t* pool, const KOut& out,
+                                   const KState& st, const unsigned long long* cell_info,
+                                   const uint8_t* actions, const uint8_t* order, int K,
+                                   int auto_reset, const uint8_t* pool, const KOut& out,
                                    unsigned long long* counters) {
     const bool pair = (p.N % 2) == 0;
-    dim3 grid(ls.num_blocks), block(64 * ls.waves_per_block);
-    if (pair)
-        hipLaunchKernelGGL((rollout_kernel<GLOG, true>), grid, block, ls.lds_bytes, stream, p, st,
-                           actions, order, K, auto_reset, pool, out, counters);
-    else
-        hipLaunchKernelGGL((rollout_kernel<GLOG, false>), grid, block, ls.lds_bytes, stream, p, st,
-                           actions, order, K, auto_reset, pool, out, counters);
-    return hipGetLastError();
+    const bool want_out = out.obs || out.reward || out.agent_flags || out.env_flags;
+#define CCX_GO(P_, O_)                                                                           \
+    return launch_rollout_v<GLOG, P_, O_>(ls, stream, p, st, cell_info, actions, order, K,       \
+                                          auto_reset, pool, out, counters)
+    if (pair && want_out) CCX_GO(true, true);
+    if (pair && !want_out) CCX_GO(true, false);
+    if (!pair && want_out) CCX_GO(false, true);
+    CCX_GO(false, false);
+#undef CCX_GO
 }
 
 template <int GLOG>
@@ -605,24 +767,25 @@ static hipError_t launch_observe_g(const LaunchShape& ls, hipStream_t stream, co
     const bool pair = (p.N % 2) == 0;
     dim3 grid(ls.num_blocks), block(64 * ls.waves_per_block);
     if (pair)
-        hipLaunchKernelGGL((observe_kernel<GLOG, true>), grid, block, ls.lds_bytes, stream, p, st, obs);
+        hipLaunchKernelGGL((observe_kernel<GLOG, true>), grid, block, ls.lds_bytes_observe, stream, p, st, obs);
     else
-        hipLaunchKernelGGL((observe_kernel<GLOG, false>), grid, block, ls.lds_bytes, stream, p, st, obs);
+        hipLaunchKernelGGL((observe_kernel<GLOG, false>), grid, block, ls.lds_bytes_observe, stream, p, st, obs);
     return hipGetLastError();
 }
 
 hipError_t launch_rollout(const LaunchShape& ls, hipStream_t stream, const KParams& p,
-                          const KState& st, const uint8_t* actions, const uint8_t* order, int K,
+                          const KState& st, const unsigned long long* cell_info,
+                          const uint8_t* actions, const uint8_t* order, int K,
                           int auto_reset, const uint8_t* pool, const KOut& out,
                           unsigned long long* counters) {
     switch (ls.glog) {
-    case 0: return launch_rollout_g<0>(ls, stream, p, st, actions, order, K, auto_reset, pool, out, counters);
-    case 1: return launch_rollout_g<1>(ls, stream, p, st, actions, order, K, auto_reset, pool, out, counters);
-    case 2: return launch_rollout_g<2>(ls, stream, p, st, actions, order, K, auto_reset, pool, out, counters);
-    case 3: return launch_rollout_g<3>(ls, stream, p, st, actions, order, K, auto_reset, pool, out, counters);
-    case 4: return launch_rollout_g<4>(ls, stream, p, st, actions, order, K, auto_reset, pool, out, counters);
-    case 5: return launch_rollout_g<5>(ls, stream, p, st, actions, order, K, auto_reset, pool, out, counters);
-    case 6: return launch_rollout_g<6>(ls, stream, p, st, actions, order, K, auto_reset, pool, out, counters);
+    case 0: return launch_rollout_g<0>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
+    case 1: return launch_rollout_g<1>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
+    case 2: return launch_rollout_g<2>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
+    case 3: return launch_rollout_g<3>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
+    case 4: return launch_rollout_g<4>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
+    case 5: return launch_rollout_g<5>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
+    case 6: return launch_rollout_g<6>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
     }
     return hipErrorInvalidValue;
 }

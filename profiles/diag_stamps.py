@@ -37,10 +37,10 @@ env._lib.ccx_counters_device_ptr(env._h, C.byref(p))
 from collectivecrossing_amd.batched import _device_view_i64  # noqa: E402
 
 c = _device_view_i64(p.value, 16, env.device).cpu().tolist()
-names = ["0 burst wait+pack+issue (per 16 steps)", "1 proposal+exchange+pair masks", "2 ballot fixed point",
-         "3 tail", "4 reward/flag stores", "5 obs gather+stores", "6 reset+env flag", "7 loop top/order"]
-tot = sum(c[8:16])
+names = ["sim 0 loop top+proposal+exchange+pair masks", "sim 1 ballot fixed point+move", "sim 2 tail+stage",
+         "sim 3 barrier wait (writer lag)", "wr  0 barrier wait (sim)", "wr  1 reward+flag stores",
+         "wr  2 obs gather+stores", "wr  3 -"]
 print(f"launch shape {env.launch_shape()}  kernel {env.last_launch_ms():.3f} ms for {K} steps (stamped build)")
 for n, v in zip(names, c[8:16]):
-    print(f"  {n:45s} {v / K:9.1f} ticks/step  {100.0 * v / tot:5.1f}%")
-print(f"  total {tot / K:.1f} ticks/step (s_memtime ticks; 100 MHz realtime or shader clock, see guide)")
+    print(f"  {n:52s} {v / K:9.1f} ticks/step")
+print(f"  sim total {sum(c[8:12]) / K:.1f}  writer total {sum(c[12:16]) / K:.1f} ticks/step")
