@@ -1,0 +1,351 @@
+"""Drop-in ``CollectiveCrossingEnv``: the reference's dict / MultiAgentEnv API over libccx.
+
+Same constructor, ``reset`` / ``step`` signatures, agent ids, key-presence rules and attributes as
+``collectivecrossing.CollectiveCrossingEnv`` (collectivecrossing.py:30-783), so
+``lambda env_config: CollectiveCrossingEnv(config=CollectiveCrossingConfig(**env_config))``
+(examples/training_script.py:26-29) keeps working.  One instance = a batch of ONE env on the GPU:
+``step`` builds the action / move-order arrays from the dict, launches ``ccx_step`` and decodes the
+flag bytes back into the five dicts.  There is no CPU implementation of ``step`` in this class --
+without the MI355X and libccx it raises.  For throughput use :class:`BatchedCollectiveCrossing`.
+
+Deliberate differences (documented in DESIGN.md):
+  * actions are validated for the WHOLE dict before anything moves (the reference validates
+    interleaved with moving, :197-202, so a bad entry leaves earlier agents moved and
+    ``_step_count`` incremented); the ``ValueError`` messages keep the reference's wording.
+  * the key order of ``observations`` / ``infos`` is slot order (the reference iterates a ``set``
+    of strings, :243, so its order changes with PYTHONHASHSEED); values are identical.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _abi
+from .actions import ACTION_TO_DIRECTION
+from .batched import BatchedCollectiveCrossing
+from .configs import CollectiveCrossingConfig
+from .params import agent_ids, calculate_tram_boundaries
+from .reset import make_generator, sample_initial_positions
+from .spaces import Discrete
+from .strategies import (get_observation_function, get_reward_function, get_terminated_function,
+                         get_truncated_function)
+from .types import Agent, AgentType
+
+try:  # RLlib is optional; with it the class is a real MultiAgentEnv
+    from ray.rllib.env.multi_agent_env import MultiAgentEnv as _Base  # type: ignore
+except Exception:
+    _Base = object
+
+
+class _Mirror:
+    """Host copy of the one-env SoA state; ``dirty`` = must be uploaded before the next launch."""
+
+    FIELDS = ("x", "y", "active", "terminated", "truncated")
+
+    def __init__(self, n: int):
+        self.x = np.zeros(n, np.int32)
+        self.y = np.zeros(n, np.int32)
+        self.active = np.ones(n, np.uint8)
+        self.terminated = np.zeros(n, np.uint8)
+        self.truncated = np.zeros(n, np.uint8)
+        self.step_count = 0
+        self.dirty = True
+
+    def write(self, name: str, index: int, value: int) -> None:
+        getattr(self, name)[index] = value
+        self.dirty = True
+
+
+def decode_step(ids, obs, reward, agent_flags, env_flag, agent_types):
+    """Flag bytes + arrays of ONE env -> the reference's five dicts (collectivecrossing.py:214-261).
+
+    Pure function (also exercised on CPU by the tests with oracle-produced arrays):
+    ``rewards`` / ``truncateds`` only hold agents that were live before the step (CCX_AF_LIVE),
+    ``terminateds`` holds everybody, ``observations`` / ``infos`` hold CCX_AF_OBS agents, and both
+    flag dicts get ``"__all__"``.
+    """
+    observations, rewards, terminateds, truncateds, infos = {}, {}, {}, {}, {}
+    for i, aid in enumerate(ids):
+        f = int(agent_flags[i])
+        terminateds[aid] = bool(f & _abi.AF_TERMINATED)
+        if f & _abi.AF_LIVE:
+            rewards[aid] = float(reward[i])
+            truncateds[aid] = bool(f & _abi.AF_TRUNCATED)
+        if f & _abi.AF_OBS:
+            observations[aid] = np.array(obs[i], dtype=np.float32)
+            infos[aid] = {"agent_type": agent_types[i], "in_tram_area": bool(f & _abi.AF_IN_TRAM_AREA),
+                          "at_door": bool(f & _abi.AF_AT_DOOR), "active": bool(f & _abi.AF_ACTIVE),
+                          "at_destination": bool(f & _abi.AF_AT_DEST)}
+    terminateds["__all__"] = bool(env_flag & _abi.EF_ALL_TERMINATED)
+    truncateds["__all__"] = bool(env_flag & _abi.EF_ALL_TRUNCATED)
+    return observations, rewards, terminateds, truncateds, infos
+
+
+def encode_actions(ids, action_dict):
+    """``action_dict`` -> (actions u8 [N] with 255 = absent, move order u8 [N]); raises the
+    reference's ``ValueError``s (collectivecrossing.py:685-711), agent check before action check."""
+    slot = {aid: i for i, aid in enumerate(ids)}
+    n = len(ids)
+    actions = np.full(n, _abi.ACTION_ABSENT, np.uint8)
+    order = []
+    for aid, action in action_dict.items():
+        if aid not in slot:
+            raise ValueError(f"Unknown agent ID: {aid} in action_dict. The action_dict keys must be a "
+                             f"subset of the agents. Current agents: {dict.fromkeys(ids).keys()}")
+        if action not in ACTION_TO_DIRECTION:
+            raise ValueError(f"Invalid action: {action} for agent {aid}. Valid actions are: "
+                             f"{list(ACTION_TO_DIRECTION)}")
+        actions[slot[aid]] = int(action)
+        order.append(slot[aid])
+    listed = set(order)
+    order += [i for i in range(n) if i not in listed]
+    return actions, np.asarray(order, np.uint8)
+
+
+class CollectiveCrossingEnv(_Base):
+    """Multi-agent tram boarding / exiting grid world, one env instance on the GPU."""
+
+    metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 4}
+
+    def __init__(self, config: CollectiveCrossingConfig, device: int | str | None = None):
+        self._config = config
+        self._tram_boundaries = calculate_tram_boundaries(config)
+        self._action_to_direction = ACTION_TO_DIRECTION
+        # unknown strategy names raise ValueError here, like the reference (:69-78)
+        self._observation_function = get_observation_function(config.observation_config)
+        self._reward_function = get_reward_function(config.reward_config)
+        self._terminated_function = get_terminated_function(config.terminated_config)
+        self._truncated_function = get_truncated_function(config.truncated_config)
+        self._ids = agent_ids(config)
+        nb = config.num_boarding_agents
+        self._types = [AgentType.BOARDING if i < nb else AgentType.EXITING for i in range(len(self._ids))]
+        self._type_names = [t.value for t in self._types]
+        self._mirror = _Mirror(len(self._ids))
+        self._agents: dict[str, Agent] = {aid: Agent(self._mirror, i, aid, self._types[i])
+                                          for i, aid in enumerate(self._ids)}
+        self._agents_truncated_or_terminated_this_step: set[str] = set()
+        self._setup_spaces()
+        if _Base is not object:
+            super().__init__()
+        gpu_config = config
+        if self._reward_function.kernel_mode is None:
+            # user-registered reward: the kernel computes the default reward, step() overrides it
+            from .configs import DefaultRewardConfig
+            gpu_config = config.model_copy(update={"reward_config": DefaultRewardConfig()})
+        for fn, what in ((self._terminated_function, "termination"), (self._truncated_function, "truncation")):
+            if fn.kernel_mode is None:
+                raise NotImplementedError(f"user-defined {what} strategies change the state transition and "
+                                          "are not supported by the GPU step")
+        self._batch = BatchedCollectiveCrossing(gpu_config, 1, device=device)
+        self.np_random: np.random.Generator | None = None
+        self._window = None
+        self._clock = None
+
+    # ------------------------------------------------------------------ reference properties
+    config = property(lambda self: self._config)
+    tram_boundaries = property(lambda self: self._tram_boundaries)
+    tram_door_left = property(lambda self: self._tram_boundaries.tram_door_left)
+    tram_door_right = property(lambda self: self._tram_boundaries.tram_door_right)
+    tram_left = property(lambda self: self._tram_boundaries.tram_left)
+    tram_right = property(lambda self: self._tram_boundaries.tram_right)
+    action_spaces = property(lambda self: self._action_spaces)
+    observation_spaces = property(lambda self: self._observation_spaces)
+
+    @property
+    def _step_count(self) -> int:
+        return self._mirror.step_count
+
+    @_step_count.setter
+    def _step_count(self, value: int) -> None:
+        self._mirror.step_count = int(value)
+        self._mirror.dirty = True
+
+    @property
+    def agents(self) -> list[str]:
+        """Ids that are neither terminated nor truncated (collectivecrossing.py:743-768)."""
+        m = self._mirror
+        return [aid for i, aid in enumerate(self._ids) if not m.terminated[i] and not m.truncated[i]]
+
+    @property
+    def possible_agents(self) -> list[str]:
+        return list(self._ids)
+
+    def get_observation_space(self, agent_id):
+        return self.observation_space
+
+    def get_action_space(self, agent_id):
+        return self.action_space
+
+    def _setup_spaces(self) -> None:
+        self._action_spaces = {aid: Discrete(5) for aid in self._ids}
+        self._observation_spaces = {
+            aid: self._observation_function.return_agent_observation_space(aid, self) for aid in self._ids}
+        if self._ids:
+            self.action_space = self._action_spaces[self._ids[0]]
+            self.observation_space = self._observation_spaces[self._ids[0]]
+
+    # ------------------------------------------------------------------ state sync
+    def _upload(self) -> None:
+        m = self._mirror
+        if m.dirty:
+            self._batch.set_state(x=m.x, y=m.y, active=m.active, terminated=m.terminated,
+                                  truncated=m.truncated, step_count=[m.step_count])
+            m.dirty = False
+
+    def _download(self) -> None:
+        st = self._batch.get_state()
+        m = self._mirror
+        for k in _Mirror.FIELDS:
+            getattr(m, k)[:] = st[k][0]
+        m.step_count = int(st["step_count"][0])
+        m.dirty = False
+
+    # ------------------------------------------------------------------ reset / step
+    def reset(self, *, seed: int | None = None, options: dict | None = None):
+        """Seeded rejection-sampled placement (collectivecrossing.py:91-159), bit-identical."""
+        if seed is not None or self.np_random is None:
+            self.np_random = make_generator(seed)        # gymnasium.Env.reset(seed=...)
+        pos = sample_initial_positions(self._config, self.np_random)
+        m = self._mirror
+        m.x[:], m.y[:] = pos[:, 0], pos[:, 1]
+        m.active[:] = 1
+        m.terminated[:] = 0
+        m.truncated[:] = 0
+        m.step_count = 0
+        m.dirty = True
+        self._upload()
+        obs = self._batch.observe().cpu().numpy()[0]
+        observations = {aid: np.array(obs[i]) for i, aid in enumerate(self._ids)}
+        infos = {aid: {"agent_type": self._type_names[i]} for i, aid in enumerate(self._ids)}
+        return observations, infos
+
+    def step(self, action_dict):
+        """One tick (collectivecrossing.py:161-261) on the GPU."""
+        actions, order = encode_actions(self._ids, action_dict)
+        self._upload()
+        res = self._batch.step(actions[None, :], order[None, :])
+        obs = res.obs.cpu().numpy()[0]
+        reward = res.reward.cpu().numpy()[0]
+        af = res.agent_flags.cpu().numpy()[0]
+        ef = int(res.env_flags.cpu().numpy()[0])
+        before_done = self._mirror.terminated | self._mirror.truncated
+        self._download()
+        out = decode_step(self._ids, obs, reward, af, ef, self._type_names)
+        now_done = self._mirror.terminated | self._mirror.truncated
+        self._agents_truncated_or_terminated_this_step = {
+            aid for i, aid in enumerate(self._ids) if now_done[i] and not before_done[i]}
+        out = self._apply_custom_strategies(out)
+        return out
+
+    def _apply_custom_strategies(self, out):
+        """User-registered strategies (no kernel_mode): evaluate on the synced mirror (slow path)."""
+        observations, rewards, terminateds, truncateds, infos = out
+        if self._reward_function.kernel_mode is None:
+            for aid in list(rewards):
+                r = self._reward_function.calculate_reward(aid, self)
+                if r is None:
+                    rewards.pop(aid)
+                else:
+                    rewards[aid] = r
+        if self._observation_function.kernel_mode is None:
+            for aid in observations:
+                observations[aid] = self._observation_function.get_agent_observation(aid, self)
+        return observations, rewards, terminateds, truncateds, infos
+
+    def close(self) -> None:
+        batch = getattr(self, "_batch", None)
+        if batch is not None:
+            batch.close()
+
+    def render(self, mode: str = "rgb_array"):
+        """Rendering is matplotlib drawing in the reference (rendering.py) and never on the step
+        path; it is out of scope here."""
+        if mode not in ("rgb_array", "human"):
+            raise NotImplementedError(f"Render mode {mode} not supported")
+        raise NotImplementedError("rendering is out of scope of collectivecrossing_amd (SURVEY 2, row 9)")
+
+    # ------------------------------------------------------------------ host views used by callers
+    def _get_agent(self, agent_id) -> Agent:
+        if agent_id in self._agents:
+            return self._agents[agent_id]
+        raise ValueError(f"Unknown agent ID: {agent_id}")
+
+    def _get_agent_position(self, agent_id) -> np.ndarray:
+        return self._get_agent(agent_id).position
+
+    def _get_agents_by_type(self, agent_type):
+        return [a for a in self._agents.values() if a.agent_type == agent_type]
+
+    def _get_boarding_agents(self):
+        return self._get_agents_by_type(AgentType.BOARDING)
+
+    def _get_exiting_agents(self):
+        return self._get_agents_by_type(AgentType.EXITING)
+
+    def _get_agent_observation(self, agent_id) -> np.ndarray:
+        return self._observation_function.get_agent_observation(agent_id, self)
+
+    def _check_action_and_agent_validity(self, agent_id, action) -> None:
+        encode_actions(self._ids, {agent_id: action})
+
+    def _is_valid_position(self, pos) -> bool:
+        x, y = int(pos[0]), int(pos[1])
+        c, tb = self._config, self._tram_boundaries
+        if not (0 <= x <= c.width and 0 <= y <= c.height):
+            return False
+        if y == c.division_y and not (tb.tram_door_left < x < tb.tram_door_right):
+            return False
+        return not (y >= c.division_y and not (tb.tram_left < x < tb.tram_right))
+
+    def _is_position_occupied(self, pos, exclude_agent=None) -> bool:
+        x, y = int(pos[0]), int(pos[1])
+        return any(a.active and a.id != exclude_agent and a.x == x and a.y == y
+                   for a in self._agents.values())
+
+    def _would_hit_tram_wall(self, current_pos, new_pos) -> bool:
+        x, y = int(new_pos[0]), int(new_pos[1])
+        c, tb = self._config, self._tram_boundaries
+        if y == c.division_y:
+            return not (tb.tram_door_left < x < tb.tram_door_right)
+        return y > c.division_y and x in (tb.tram_left, tb.tram_right)
+
+    def _is_move_valid(self, agent_id, current_pos, new_pos) -> bool:
+        return (self._is_valid_position(new_pos) and
+                not self._is_position_occupied(new_pos, exclude_agent=agent_id) and
+                not self._would_hit_tram_wall(current_pos, new_pos))
+
+    def _calculate_new_position(self, agent_id, action) -> np.ndarray:
+        return self._get_agent_position(agent_id) + self._action_to_direction[action]
+
+    def is_in_boarding_destination_area(self, agent_id) -> bool:
+        return self._get_agent(agent_id).y == self._config.boarding_destination_area_y
+
+    def is_in_exiting_destination_area(self, agent_id) -> bool:
+        return self._get_agent(agent_id).y == self._config.exiting_destination_area_y
+
+    def is_in_tram_area(self, agent_id) -> bool:
+        a = self._get_agent(agent_id)
+        return a.y >= self._config.division_y and self.tram_left <= a.x <= self.tram_right
+
+    def is_at_tram_door(self, agent_id) -> bool:
+        a = self._get_agent(agent_id)
+        return a.y == self._config.division_y and a.x in (self.tram_door_left - 1, self.tram_door_right + 1)
+
+    def get_agent_destination_position(self, agent_id):
+        if self._agents[agent_id].is_boarding:
+            return (None, self._config.boarding_destination_area_y)
+        return (None, self._config.exiting_destination_area_y)
+
+    def has_agent_reached_destination(self, agent_id) -> bool:
+        if self._agents[agent_id].is_boarding:
+            return self.is_in_boarding_destination_area(agent_id)
+        return self.is_in_exiting_destination_area(agent_id)
+
+    def _calculate_reward(self, agent_id):
+        return self._reward_function.calculate_reward(agent_id, self)
+
+    def _calculate_terminated(self, agent_id):
+        return self._terminated_function.calculate_terminated(agent_id, self)
+
+    def _calculate_truncated(self, agent_id):
+        return self._truncated_function.calculate_truncated(agent_id, self)
