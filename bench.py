@@ -111,7 +111,7 @@ def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=250)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--chunk", type=int, default=250, help="env-steps fused per kernel launch")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave carrying agents (0=auto)")
