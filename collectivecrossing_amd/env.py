@@ -59,7 +59,7 @@ class _Mirror:
 def decode_step(ids, obs, reward, agent_flags, env_flag, agent_types):
     """Flag bytes + arrays of ONE env -> the reference's five dicts (collectivecrossing.py:214-261).
 
-    Pure function (also exercised on CPU by the tests with oracle-produced arrays):
+    Pure function (the CPU test-suite exercises it without a GPU):
     ``rewards`` / ``truncateds`` only hold agents that were live before the step (CCX_AF_LIVE),
     ``terminateds`` holds everybody, ``observations`` / ``infos`` hold CCX_AF_OBS agents, and both
     flag dicts get ``"__all__"``.
