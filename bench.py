@@ -44,6 +44,34 @@ def c2_config(max_steps: int = 100):
         boarding_destination_area_y=8, truncated_config=MaxStepsTruncatedConfig(max_steps=max_steps))
 
 
+def workload_config(name: str):
+    """Named workloads: c2 is THE bench line (BASELINE configs[1]); the others are the remaining
+    BASELINE configs, available for diagnostics (`--workload`), never the default."""
+    from collectivecrossing_amd import configs as C
+    if name == "c2":
+        return c2_config(), 4096
+    if name == "c3":   # configs[2]: 20x12, 16+16, SimpleDistance (dense collisions)
+        return C.CollectiveCrossingConfig(
+            width=20, height=12, division_y=6, tram_door_left=6, tram_door_right=10, tram_length=16,
+            num_boarding_agents=16, num_exiting_agents=16, exiting_destination_area_y=0,
+            boarding_destination_area_y=12,
+            reward_config=C.SimpleDistanceRewardConfig(distance_penalty_factor=0.1),
+            truncated_config=C.MaxStepsTruncatedConfig(max_steps=100)), 4096
+    if name in ("c5_50", "c5_64"):   # configs[4] geometry: 32x16, AllAtDestination, MaxSteps=500
+        nb = 25 if name == "c5_50" else 32
+        kw = dict(width=32, height=16, division_y=8, tram_door_left=10, tram_door_right=16,
+                  tram_length=26, num_boarding_agents=nb, num_exiting_agents=nb,
+                  exiting_destination_area_y=0, boarding_destination_area_y=16,
+                  terminated_config=C.AllAtDestinationTerminatedConfig(),
+                  truncated_config=C.MaxStepsTruncatedConfig(max_steps=500),
+                  observation_config=C.DefaultObservationConfig(), reward_config=C.DefaultRewardConfig(),
+                  render_mode=None)
+        if nb == 32:   # 64 agents exceed the reference's limit of 50 (configs.py:166): skip validation
+            return C.CollectiveCrossingConfig.model_construct(**kw), 1024
+        return C.CollectiveCrossingConfig(**kw), 1024
+    raise SystemExit(f"unknown workload {name}")
+
+
 def rollout_bytes_per_agent_step(n_agents: int) -> int:
     """Bytes one fused rollout launch MUST move per agent-step (state stays in registers):
     observation row 4*(6+4N) + action 1 + reward f64 8 + agent flag byte 1 (+ 1/N env flag byte,
@@ -112,10 +140,12 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=250)
-    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the workload's own size")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5_50", "c5_64"])
     ap.add_argument("--chunk", type=int, default=250, help="env-steps fused per kernel launch")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave carrying agents (0=auto)")
-    ap.add_argument("--wpb", type=int, default=0, help="waves per workgroup (0=auto)")
+    ap.add_argument("--wpb", type=int, default=0, help="env tiles per workgroup (0=auto)")
+    ap.add_argument("--writers", type=int, default=0, help="writer waves per env tile (0=auto)")
     ap.add_argument("--pool", type=int, default=4096, help="reset-pool entries (seeds 0..pool-1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip the observation output")
@@ -133,13 +163,15 @@ def main() -> int:
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    config = c2_config()
-    E = args.envs_per_gpu
+    config, E_default = workload_config(args.workload)
+    E = args.envs_per_gpu or E_default
     total = E * world
     env = BatchedCollectiveCrossing(config, E, device=dev, env_offset=rank * E, total_envs=total)
     N, L = env.num_agents, env.obs_len
     if args.lanes or args.wpb:
         env.set_launch_shape(args.lanes, args.wpb)
+    if args.writers:
+        env.set_writers(args.writers)
     env.set_reset_pool(build_reset_pool(config, 0, args.pool))
     env.reset_from_pool()
 
@@ -199,30 +231,31 @@ def main() -> int:
         assert counters["env_steps"] == args.steps * total, counters
         env_sps = args.steps * total / elapsed
         line = {
-            "metric": "env-steps/sec, random-action rollout, 4096 envs x 8 agents per GPU",
+            "metric": f"env-steps/sec, random-action rollout, {E} envs x {N} agents per GPU",
             "value": env_sps, "unit": "env-steps/s", "agent_steps_per_sec": env_sps * N,
             "live_agent_steps_per_sec": counters["live_agent_steps"] / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32 state / f32 obs / f64 reward",
             "data": "synthetic",
-            "config": {"workload": "C2: 4096 envs x (5 boarding + 3 exiting) per GPU, 12x8 grid, "
-                                   "DefaultReward + DefaultObservation, individual_at_destination, "
-                                   "max_steps=100, uniform random actions, auto-reset from "
-                                   f"{args.pool} reference-exact seeded placements",
+            "config": {"workload": ("C2: 4096 envs x (5 boarding + 3 exiting) per GPU, 12x8 grid, "
+                                    "DefaultReward + DefaultObservation, individual_at_destination, "
+                                    "max_steps=100, uniform random actions, auto-reset from "
+                                    f"{args.pool} reference-exact seeded placements") if args.workload == "c2"
+                       else f"{args.workload} (diagnostic, not the bench line)",
                        "envs_per_gpu": E, "global_envs": total, "agents": N, "obs_len": L,
                        "steps_per_launch": chunk, "launch_shape": env.launch_shape(),
                        "outputs": "full trajectory" + (" (no obs)" if args.no_obs else "")},
             "counters": counters,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ccx::rollout_kernel<3,true>", "kernel_ms_per_launch": kern_ms,
+                         "kernel": "ccx::rollout_kernel", "kernel_ms_per_launch": kern_ms,
                          "bytes_per_agent_step": bytes_unit, "bytes_per_launch": launch_bytes,
                          "achieved_survey_8d_GBs": (survey_unit * chunk * E * N / (kern_ms * 1e-3) / 1e9
                                                     if full else None),
                          "survey_8d_bytes_per_agent_step": survey_unit},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "c2":
             line["cpu_baseline"] = cpu_baseline(config, N)
         elif world > 1:
             line["cpu_baseline"] = None

@@ -101,6 +101,7 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_counters_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "ccx_last_launch_ms": (C.c_int, [_H, C.POINTER(C.c_float)]),
     "ccx_set_launch_shape": (C.c_int, [_H, C.c_int32, C.c_int32]),
+    "ccx_set_writers": (C.c_int, [_H, C.c_int32]),
     "ccx_get_launch_shape": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccx_synchronize": (C.c_int, [_H]),

@@ -232,6 +232,9 @@ class BatchedCollectiveCrossing:
     def set_launch_shape(self, lanes_per_wave: int = 0, waves_per_block: int = 0) -> None:
         check(self._lib.ccx_set_launch_shape(self._h, lanes_per_wave, waves_per_block))
 
+    def set_writers(self, writers_per_tile: int = 0) -> None:
+        check(self._lib.ccx_set_writers(self._h, writers_per_tile))
+
     def launch_shape(self) -> dict[str, int]:
         v = [C.c_int32() for _ in range(4)]
         check(self._lib.ccx_get_launch_shape(self._h, *[C.byref(x) for x in v]))

@@ -55,7 +55,7 @@ struct ccx_handle {
     int64_t pool_size = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
-    int lanes_per_wave = 0, waves_per_block = 0;  // user overrides (0 = default)
+    int lanes_per_wave = 0, waves_per_block = 0, writers = 0;  // user overrides (0 = default)
     ccx::LaunchShape shape{};
     ccx::KParams kp{};
 };
@@ -68,14 +68,18 @@ namespace {
 std::vector<unsigned long long> build_cell_table(const ccx_params& p) {
     const int Wp = p.width + 3, Hp = p.height + 3;
     const int dc = (p.door_left + p.door_right) / 2;
+    auto cell_ok = [&](int x, int y) {   // collectivecrossing.py:509-534
+        if (!(x >= 0 && x <= p.width && y >= 0 && y <= p.height)) return false;
+        if (y == p.division_y && !(p.door_left < x && x < p.door_right)) return false;
+        if (y >= p.division_y && !(p.tram_left < x && x < p.tram_right)) return false;
+        return true;
+    };
+    static const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1};   // actions.py:18-24
     std::vector<unsigned long long> tab((size_t)Wp * Hp, 0ull);
-    for (int y = -1; y <= p.height + 1; ++y)
-        for (int x = -1; x <= p.width + 1; ++x) {
-            const bool inside = x >= 0 && x <= p.width && y >= 0 && y <= p.height;
-            if (!inside) continue;  // border: VALID = 0, never occupied
-            bool valid = true;
-            if (y == p.division_y && !(p.door_left < x && x < p.door_right)) valid = false;
-            if (y >= p.division_y && !(p.tram_left < x && x < p.tram_right)) valid = false;
+    for (int y = 0; y <= p.height; ++y)
+        for (int x = 0; x <= p.width; ++x) {   // border cells stay 0: never occupied
+            unsigned nv = 0;
+            for (int a = 0; a < 4; ++a) nv |= (cell_ok(x + DX[a], y + DY[a]) ? 1u : 0u) << a;
             const bool in_area = y >= p.division_y && p.tram_left <= x && x <= p.tram_right;
             const bool at_door = y == p.division_y && (x == p.door_left - 1 || x == p.door_right + 1);
             const bool dest_b = y == p.boarding_dest_y, dest_e = y == p.exiting_dest_y;
@@ -92,7 +96,7 @@ std::vector<unsigned long long> build_cell_table(const ccx_params& p) {
                 sd_b = -(y > p.boarding_dest_y ? y - p.boarding_dest_y : p.boarding_dest_y - y);
                 sd_e = -(y > p.exiting_dest_y ? y - p.exiting_dest_y : p.exiting_dest_y - y);
             }
-            unsigned lo = (valid ? 1u : 0u) | (in_area ? 0x10u : 0u) | (at_door ? 0x20u : 0u) |
+            unsigned lo = nv | (in_area ? 0x10u : 0u) | (at_door ? 0x20u : 0u) |
                           ((dest_b ? 1u : 0u) << 8) | (cls_b << 9) | ((dest_e ? 1u : 0u) << 12) |
                           (cls_e << 13) | ((unsigned)x << 16) | ((unsigned)y << 24);
             unsigned hi = ((unsigned)sd_b & 0xFFFFu) | (((unsigned)sd_e & 0xFFFFu) << 16);
@@ -120,20 +124,40 @@ void choose_shape(ccx_handle* h) {
     }
     if (ew < 1) ew = 1;
     if (ew > max_ew) ew = max_ew;
-    const int waves = (h->E + ew - 1) / ew;
-    int wpb = h->waves_per_block > 0 ? h->waves_per_block : (waves > 8192 ? 2 : 1);
-    if (wpb > 4) wpb = 4;
+    const int tiles = (h->E + ew - 1) / ew;
+    // writer waves per tile: enough that a writer handles <= ~6 store iterations per step
+    const int units = ew * h->N * (3 + 2 * h->N);
+    const int n4 = (h->N % 2 == 0) ? units / 2 : units;
+    int writers = h->writers > 0 ? h->writers : (n4 > 64 * 24 ? 3 : n4 > 64 * 6 ? 2 : 1);
+    if (writers > 3) writers = 3;
+    int tpb = h->waves_per_block > 0 ? h->waves_per_block : (tiles > 8192 ? 2 : 1);
+    while (tpb > 1 && tpb * (1 + writers) > 8) --tpb;   // <= 512 threads per workgroup
     ccx::LaunchShape& s = h->shape;
     s.glog = glog;
     s.envs_per_wave = ew;
-    s.waves_per_block = wpb;
-    s.num_blocks = (waves + wpb - 1) / wpb;
-    const int units = ew * h->N * (3 + 2 * h->N);
-    const size_t table = (size_t)(units + 2) * 2u;
+    s.waves_per_block = tpb;
+    s.writers = writers;
+    s.num_blocks = (tiles + tpb - 1) / tpb;
+
+    // LDS carve-up (see ccx_kernels.hip): [cell table][tiles][u16 obs table]
+    auto up16 = [](size_t v) { return (v + 15u) & ~(size_t)15u; };
     const size_t cells = (size_t)(h->params.width + 3) * (size_t)(h->params.height + 3);
-    s.lds_bytes_observe = ((size_t)wpb * 1312u + table + 15u) & ~(size_t)15u;      // WaveLds
-    s.lds_bytes = ((cells * 8u + 15u) & ~(size_t)15u) +
-                  (((size_t)wpb * 3360u + table + 15u) & ~(size_t)15u);             // TileLds
+    const size_t msz = (glog == 6) ? 8u : 4u;
+    const size_t occ_bytes = up16((size_t)ew * 2u * (cells + 1u) * msz);
+    const size_t table = up16((size_t)(units + 2) * 2u);
+    const size_t off_tiles = up16(cells * 8u);
+    const size_t off_ws = 256u + 2048u;                         // xch + stage
+    const size_t off_occ = off_ws + (size_t)writers * 1056u;    // WSlot per writer
+    size_t tile_stride = up16(off_occ + occ_bytes);
+    size_t total = off_tiles + (size_t)tpb * tile_stride + table;
+    s.occ = 1;
+    if (total > 96u * 1024u) {          // tables too big: all-pairs conflict masks instead
+        s.occ = 0;
+        tile_stride = up16(off_occ);
+        total = off_tiles + (size_t)tpb * tile_stride + table;
+    }
+    s.lds_bytes = total;
+    s.lds_bytes_observe = up16((size_t)tpb * 1056u + table);
 
     ccx::KParams& k = h->kp;
     const ccx_params& p = h->params;
@@ -142,7 +166,12 @@ void choose_shape(ccx_handle* h) {
     k.dc = (p.door_left + p.door_right) / 2;  // observations.py:70-71, rewards.py:81
     k.Nb = p.num_boarding; k.N = h->N; k.bdy = p.boarding_dest_y; k.edy = p.exiting_dest_y;
     k.reward_mode = p.reward_mode; k.term_mode = p.terminated_mode; k.max_steps = p.max_steps;
-    k.E = h->E; k.EW = ew; k.waves_per_block = wpb; k.units_per_wave = units; k._pad = 0;
+    k.E = h->E; k.EW = ew; k.waves_per_block = tpb; k.units_per_wave = units; k.writers = writers;
+    k.off_tiles = (uint32_t)off_tiles; k.tile_stride = (uint32_t)tile_stride;
+    k.off_ws = (uint32_t)off_ws; k.off_occ = (uint32_t)off_occ;
+    k.occ_words = s.occ ? (uint32_t)(occ_bytes / 4u) : 0u;
+    k.off_table = (uint32_t)(off_tiles + (size_t)tpb * tile_stride);
+    k._pad[0] = k._pad[1] = 0;
     k.r_dest = p.boarding_destination_reward; k.r_door = p.tram_door_reward;
     k.r_area = p.tram_area_reward; k.r_f = p.distance_penalty_factor;
     k.r_nogoal = p.no_goal_reward; k.r_pen = p.step_penalty;
@@ -466,6 +495,14 @@ int ccx_set_launch_shape(ccx_handle* h, int32_t lanes_per_wave, int32_t waves_pe
     if (waves_per_block < 0 || waves_per_block > 4) return fail(CCX_EINVAL, "waves_per_block must be 0..4");
     h->lanes_per_wave = lanes_per_wave;
     h->waves_per_block = waves_per_block;
+    choose_shape(h);
+    return CCX_OK;
+}
+
+int ccx_set_writers(ccx_handle* h, int32_t writers_per_tile) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if (writers_per_tile < 0 || writers_per_tile > 3) return fail(CCX_EINVAL, "writers_per_tile must be 0..3");
+    h->writers = writers_per_tile;
     choose_shape(h);
     return CCX_OK;
 }

@@ -20,7 +20,13 @@ struct KParams {
     int EW;                              // envs carried by one wavefront
     int waves_per_block;
     int units_per_wave;                  // EW * N * (3 + 2N) float2 units of observation per wave
-    int _pad;
+    int writers;                         // writer waves per tile (rollout kernel with outputs)
+    // LDS carve-up of the rollout kernel (bytes): cell table at 0, tiles, obs table
+    uint32_t off_tiles, tile_stride;     // first tile, distance between tiles of a block
+    uint32_t off_ws, off_occ;            // within a tile: WSlot array, occupancy/proposal tables
+    uint32_t occ_words;                  // 32-bit words of one tile's occupancy+proposal tables
+    uint32_t off_table;                  // u16 obs address table
+    uint32_t _pad[2];
     double r_dest, r_door, r_area, r_f, r_nogoal, r_pen;
     long long env_offset;                // global index of env 0 (sharding)
     long long pool_size;                 // reset-pool entries (0 = none)
@@ -47,7 +53,9 @@ struct KOut {
 struct LaunchShape {
     int glog;             // log2 of the per-env lane group
     int envs_per_wave;    // EW
-    int waves_per_block;
+    int waves_per_block;  // env tiles per block (each: 1 sim wave + `writers` writer waves)
+    int writers;
+    int occ;              // 1: occupancy-table conflict masks fit in LDS
     int num_blocks;
     size_t lds_bytes;        // rollout kernel: cell table + per-wave tiles + obs table
     size_t lds_bytes_observe;  // observe kernel: per-wave tiles + obs table

@@ -8,8 +8,8 @@
 // lanes; a SIM wavefront carries EW <= 64/G envs and keeps their state in registers for all K
 // steps of a rollout.  Env tiles never talk to each other (no inter-workgroup traffic).
 //
-// A workgroup is a PAIR of wavefronts per env tile, split by role along the reference's own phase
-// boundary (collectivecrossing.py:197-212 vs :214-261):
+// A workgroup is a small TEAM of wavefronts per env tile (1 sim + 1..3 writers), split by role along
+// the reference's own phase boundary (collectivecrossing.py:197-212 vs :214-261):
 //   * the SIM wave does the state transition: action decode, ordered move resolution, arrival /
 //     termination / truncation flags, auto-reset.  It issues no global stores at all; per step it
 //     hands 16 bytes per lane (cell word, distance word, flag byte, env byte) to its partner
@@ -27,10 +27,12 @@
 //   1. every lane proposes its target cell in parallel; validity of the target (bounds, walls,
 //      door) and everything else the step needs to know about a cell is ONE ds_read_b64 from a
 //      per-cell table precomputed on the host (see "per-cell geometry table" below);
-//   2. proposals are exchanged through a 256-byte LDS tile indexed by move RANK, so lane k of a
-//      group plays "the agent moved k-th";
-//   3. each rank k builds two bit masks over earlier ranks k' < k:  P[k'] = prop_k' == prop_k,
-//      C[k'] = active_k' && cur_k' == prop_k, and tests later ranks' current cells once;
+//   2. every active agent ORs its move-rank bit into a per-env OCCUPANCY bit table (LDS, one mask
+//      per cell) at its current cell and, if its proposal is legal, into a PROPOSAL table at the
+//      target cell; reading both tables at the target gives, in O(1) per agent,
+//   3. C = earlier ranks standing on my target, P = earlier ranks proposing my target, and whether
+//      a later rank still stands there (grids whose tables exceed LDS fall back to an all-pairs
+//      compare through a 256-byte exchange tile, O(G) per agent);
 //   4. with M = mask of earlier ranks that DID move, rank k moves iff ((M & P) | (~M & C)) == 0.
 //      M is a wave ballot; F(M) has a unique fixed point reached in <= N rounds (bit k of F
 //      depends on bits < k only); the loop is skipped when no lane depends on an earlier rank and
@@ -114,20 +116,16 @@ template <typename T> __device__ __forceinline__ T in_vgpr(T v) {
     }
 }
 
-// per-tile LDS (observe kernel: WaveLds only)
-struct WaveLds {
+// LDS tiles.  WSlot: what a wave that writes observation rows gathers from (one per writer wave /
+// per wave of the observe kernel).  The rollout kernel's per-tile carve-up (byte offsets in
+// KParams): [xch u32 x 64][stage uint4 x 2 x 64][WSlot x writers][occ | prp masks x EW x (cells+1)].
+struct WSlot {
     float4 slot[64];   // (x, y, type, active) of the agent on each lane, as floats
     float cst[8];      // (door_centre, division_y) (door_left, door_right) (-1,-1) pad
-    uint32_t xch[64];  // move proposals, indexed [group_base + rank]: cur_key | prop_key << 16
 };
-static_assert(sizeof(WaveLds) == 1024 + 32 + 256, "WaveLds layout");
+static_assert(sizeof(WSlot) == 1024 + 32, "WSlot layout");
 static constexpr uint32_t kCstOff = 1024;  // byte offset of cst[] from slot[]
-
-struct TileLds {
-    WaveLds w;
-    uint4 stage[2][64];  // sim -> writer hand-off, double buffered: {cell lo, cell hi, af, ef}
-};
-static_assert(sizeof(TileLds) == 1312 + 2048, "TileLds layout");
+using WaveLds = WSlot;
 
 // u16 table entry for float2 unit `w` of a tile's observation region: byte offset (from the
 // tile's WaveLds) of the 8 bytes to copy there.  Row layout (observations.py:64-92):
@@ -215,26 +213,31 @@ constexpr int kObsBatch = 5;       // LDS reads issued back to back before their
 // ---- per-cell geometry table ------------------------------------------------------------------
 // Everything the step needs to know about a grid cell is precomputed once per handle on the host
 // (ccx_api.hip: build_cell_table) for the padded grid x in [-1, W+1], y in [-1, H+1]
-// (cell = (y+1)*(W+3) + (x+1)), copied to LDS at kernel start and looked up ONCE per agent-step
-// for the proposed cell:
-//   lo: bit0 VALID  in-grid and not a wall          (collectivecrossing.py:509-534)
+// (cell = (y+1)*(W+3) + (x+1)) and copied to LDS at kernel start:
+//   lo: bits 0-3  move a (right, up, left, down) from this cell lands on a cell that is in the
+//                 grid and not a wall                       (collectivecrossing.py:509-534)
 //       bit4 IN_TRAM_AREA (:551-554)  bit5 AT_DOOR (:556-563)       -- same bits as CCX_AF_*
 //       bit8  boarding: on destination row (:663-683)   bits 9-10  boarding reward class
 //       bit12 exiting:  on destination row              bits 13-14 exiting reward class
 //       byte2 = x, byte3 = y  (0 for border cells)
 //   hi: int16 signed distance term of the boarding reward | int16 of the exiting reward << 16
 // reward class (rewards.py:44-182): 0 = (double)sd * distance_penalty_factor, 1/2/3 = constants
-// rA/rB/rC chosen per reward mode.
+// rA/rB/rC chosen per reward mode.  The word of the agent's CURRENT cell is carried in registers,
+// so the legality of a move is a bit test; the word of the proposed cell is fetched off the
+// critical path and only consumed once the move is known to happen.
 //
 // sim -> writer hand-off (uint4 per lane and step): x = cell lo, y = cell hi, z = the CCX_AF_*
 // byte of the agent, w = the CCX_EF_* byte of its env.
 
 // ---------------------------------------------------------------------------------------------
-// the fused rollout / step kernel.  OUT = trajectory outputs requested: the workgroup then has
-// 2 * waves_per_block wavefronts, wave t < waves_per_block simulating tile t and wave
-// t + waves_per_block writing its outputs.  OUT = false: sim waves only, counters only.
+// the fused rollout / step kernel.
+//   OUT  trajectory outputs requested: a tile is served by 1 sim wave + p.writers writer waves;
+//        OUT = false: sim waves only (counters only).
+//   OCC  conflict masks come from per-env occupancy / proposal bit tables in LDS (O(1) per agent);
+//        OCC = false: all-pairs compare through the xch tile (grids whose tables exceed LDS).
+// wave index in block -> role = wib / tiles_per_block (0 = sim, 1.. = writer), tile = wib % tpb.
 // ---------------------------------------------------------------------------------------------
-template <int GLOG, bool PAIR, bool OUT>
+template <int GLOG, bool PAIR, bool OUT, bool OCC>
 __global__ void __launch_bounds__(512)
 rollout_kernel(const KParams p, const KState st, const unsigned long long* __restrict__ cell_info,
                const uint8_t* __restrict__ actions, const uint8_t* __restrict__ order, const int K,
@@ -246,9 +249,10 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
-    const bool is_writer = OUT && (wib >= p.waves_per_block);
-    const int tile_in_block = is_writer ? wib - p.waves_per_block : wib;
-    const int tile = blockIdx.x * p.waves_per_block + tile_in_block;
+    const int tpb = p.waves_per_block;                                  // tiles per block
+    const int role = OUT ? wib / tpb : 0;                               // 0 sim, 1.. writers
+    const int tile_in_block = OUT ? wib - role * tpb : wib;
+    const int tile = blockIdx.x * tpb + tile_in_block;
     const int g = lane >> GLOG;
     const int i = lane & (G - 1);
     const int gbase = g << GLOG;
@@ -266,18 +270,23 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     const uint32_t tsh2 = boarding ? 0u : 16u;    // type-specific half of the distance word
     const int Wp = p.W + 3;
 
-    // LDS carve-up: [cell table u64 x cells][TileLds x waves_per_block][u16 obs table]
+    // LDS carve-up: [cell table][tile 0 .. tile tpb-1][u16 obs table]; offsets from the host
     const uint32_t cells = (uint32_t)(Wp * (p.H + 3));
-    const uint32_t cell_bytes = (cells * 8u + 15u) & ~15u;
     unsigned long long* cinfo = reinterpret_cast<unsigned long long*>(smem);
-    TileLds* tl = reinterpret_cast<TileLds*>(smem + cell_bytes) + tile_in_block;
-    WaveLds* wl = &tl->w;
-    uint16_t* table = reinterpret_cast<uint16_t*>(smem + cell_bytes + sizeof(TileLds) * p.waves_per_block);
+    unsigned char* tbase = smem + p.off_tiles + (uint32_t)tile_in_block * p.tile_stride;
+    uint32_t* xch = reinterpret_cast<uint32_t*>(tbase);
+    uint4* stage = reinterpret_cast<uint4*>(tbase + 256);
+    uint16_t* table = reinterpret_cast<uint16_t*>(smem + p.off_table);
     const bool want_obs = OUT && out.obs != nullptr;
     for (uint32_t t = threadIdx.x; t < cells; t += blockDim.x) cinfo[t] = cell_info[t];
     if (want_obs) build_obs_table<GLOG>(table, p);
-    if (!is_writer) init_wave_consts(wl, p, lane);
-    __syncthreads();  // tables are read-only from here on
+    if constexpr (OCC) {   // zero the occupancy / proposal tables of every tile of the block
+        for (uint32_t t = threadIdx.x; t < (uint32_t)tpb * p.occ_words; t += blockDim.x) {
+            const uint32_t ti = t / p.occ_words, w = t - ti * p.occ_words;
+            reinterpret_cast<uint32_t*>(smem + p.off_tiles + ti * p.tile_stride + p.off_occ)[w] = 0u;
+        }
+    }
+    __syncthreads();  // tables are read-only / zeroed from here on
 
     int envs_here = p.E - env0;
     envs_here = envs_here < 0 ? 0 : (envs_here > p.EW ? p.EW : envs_here);
@@ -285,10 +294,15 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     const int n4 = PAIR ? (units >> 1) : units;     // vector units (16 B or 8 B) of the obs region
 
     // =========================================================================================
-    // WRITER wave: reward, flag bytes, observation rows of every step (reference phases :214-261)
+    // WRITER waves: reward, flag bytes, observation rows of every step (reference :214-261).
+    // Writer w of nw takes the store iterations it = w, w + nw, ...; writer 0 also writes the
+    // reward and the flag bytes.
     // =========================================================================================
     if constexpr (OUT) {
-        if (is_writer) {
+        if (role > 0) {
+            const int w = role - 1, nw = p.writers;
+            WSlot* wl = reinterpret_cast<WSlot*>(tbase + p.off_ws) + w;
+            init_wave_consts(wl, p, lane);
             const float type_f = boarding ? 0.0f : 1.0f;  // observations.py:85
             // reward constants (rewards.py:44-182): class 1/2/3 -> rA/rB/rC, class 0 -> sd * rF
             const int rmode = p.reward_mode;
@@ -299,34 +313,38 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             const double rF = in_vgpr(p.r_f);
             // wave-uniform base pointers advanced per step on the scalar unit + per-lane 32-bit
             // byte offsets that never change
+            const bool small_out = (w == 0);
             const uint32_t rew_off = (uint32_t)idx * 8u, af_off = (uint32_t)idx, ef_off = (uint32_t)env;
-            char* rew_s = reinterpret_cast<char*>(out.reward);
-            char* af_s = reinterpret_cast<char*>(out.agent_flags);
-            char* ef_s = reinterpret_cast<char*>(out.env_flags);
+            char* rew_s = small_out ? reinterpret_cast<char*>(out.reward) : nullptr;
+            char* af_s = small_out ? reinterpret_cast<char*>(out.agent_flags) : nullptr;
+            char* ef_s = small_out ? reinterpret_cast<char*>(out.env_flags) : nullptr;
             char* obs_s = reinterpret_cast<char*>(out.obs) + (size_t)env0 * N * L * 4;
             const size_t obs_stride = EN * (size_t)L * 4;
             // LDS source addresses of this lane's first kFastObsIters observation stores
             uint32_t oa0[kFastObsIters], oa1[kFastObsIters];
 #pragma unroll
-            for (int it = 0; it < kFastObsIters; ++it) {
-                const int q = lane + 64 * it;
-                oa0[it] = oa1[it] = kCstOff + 16u;
+            for (int j = 0; j < kFastObsIters; ++j) {
+                const int q = lane + 64 * (w + nw * j);
+                oa0[j] = oa1[j] = kCstOff + 16u;
                 if (want_obs && q < n4) {
                     if constexpr (PAIR) {
                         const uint32_t t = reinterpret_cast<const uint32_t*>(table)[q];
-                        oa0[it] = t & 0xFFFFu;
-                        oa1[it] = t >> 16;
+                        oa0[j] = t & 0xFFFFu;
+                        oa1[j] = t >> 16;
                     } else {
-                        oa0[it] = table[q];
+                        oa0[j] = table[q];
                     }
                 }
             }
+            const uint32_t vbytes = PAIR ? 16u : 8u;
+            const uint32_t q0_off = (uint32_t)(lane + 64 * w) * vbytes;   // byte offset of iteration 0
+            const uint32_t it_stride = 64u * (uint32_t)nw * vbytes;       // between my iterations
             const char* sbase = reinterpret_cast<const char*>(wl);
             CCX_STAMP_DECL;
 
             for (int s = 0; s < K; ++s) {
                 lds_barrier();                       // the sim wave has staged step s
-                const uint4 e = tl->stage[s & 1][lane];
+                const uint4 e = stage[(s & 1) * 64 + lane];
                 CCX_STAMP(0);                        // wait for the sim wave
                 const uint32_t ilo = e.x, ihi = e.y, af = e.z;
                 if (want_obs) {
@@ -334,61 +352,74 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                     wl->slot[lane] = make_float4((float)((ilo >> 16) & 0xFFu), (float)(ilo >> 24), type_f,
                                                  (float)((af >> 6) & 1u));
                 }
-                // rewards.py:44-182.  Distances are integers and the reference negates the
-                // INTEGER before the one f64 multiply, so d == 0 gives +0.0 (never -0.0).
-                const uint32_t cls = (ilo >> (tsh + 1u)) & 3u;
-                const int sd = (int)(int16_t)(uint16_t)(ihi >> tsh2);
-                double r = (double)sd * rF;
-                r = (cls == 1u) ? rA : r;
-                r = (cls == 2u) ? rB : r;
-                r = (cls == 3u) ? rC : r;
-                r = (af & 0x04u) ? r : 0.0;          // rewards.py:64: None unless live
-                if (valid) {
-                    if (rew_s) *reinterpret_cast<double*>(rew_s + rew_off) = r;
-                    if (af_s) *reinterpret_cast<uint8_t*>(af_s + af_off) = (uint8_t)af;
-                    if (ef_s && i == 0) *reinterpret_cast<uint8_t*>(ef_s + ef_off) = (uint8_t)e.w;
+                if (small_out) {
+                    // rewards.py:44-182.  Distances are integers and the reference negates the
+                    // INTEGER before the one f64 multiply, so d == 0 gives +0.0 (never -0.0).
+                    const uint32_t cls = (ilo >> (tsh + 1u)) & 3u;
+                    const int sd = (int)(int16_t)(uint16_t)(ihi >> tsh2);
+                    double r = (double)sd * rF;
+                    r = (cls == 1u) ? rA : r;
+                    r = (cls == 2u) ? rB : r;
+                    r = (cls == 3u) ? rC : r;
+                    r = (af & 0x04u) ? r : 0.0;      // rewards.py:64: None unless live
+                    if (valid) {
+                        if (rew_s) *reinterpret_cast<double*>(rew_s + rew_off) = r;
+                        if (af_s) *reinterpret_cast<uint8_t*>(af_s + af_off) = (uint8_t)af;
+                        if (ef_s && i == 0) *reinterpret_cast<uint8_t*>(ef_s + ef_off) = (uint8_t)e.w;
+                    }
+                    if (rew_s) rew_s += EN * 8;
+                    if (af_s) af_s += EN;
+                    if (ef_s) ef_s += p.E;
                 }
-                if (rew_s) rew_s += EN * 8;
-                if (af_s) af_s += EN;
-                if (ef_s) ef_s += p.E;
                 CCX_STAMP(1);                        // reward + flag bytes
                 if (want_obs) {
                     wave_lds_sync();
                     // all LDS reads of a batch first (idle lanes read the constant slot), so the
                     // wave pays one LDS latency per batch, then the stores
 #pragma unroll
-                    for (int it0 = 0; it0 < kFastObsIters; it0 += kObsBatch) {
-                        if (64 * it0 < n4) {
+                    for (int j0 = 0; j0 < kFastObsIters; j0 += kObsBatch) {
+                        if (64 * (w + nw * j0) < n4) {
                             float2 va[kObsBatch], vb[kObsBatch];
 #pragma unroll
                             for (int j = 0; j < kObsBatch; ++j) {
-                                va[j] = *reinterpret_cast<const float2*>(sbase + oa0[it0 + j]);
+                                va[j] = *reinterpret_cast<const float2*>(sbase + oa0[j0 + j]);
                                 if constexpr (PAIR)
-                                    vb[j] = *reinterpret_cast<const float2*>(sbase + oa1[it0 + j]);
+                                    vb[j] = *reinterpret_cast<const float2*>(sbase + oa1[j0 + j]);
                             }
 #pragma unroll
                             for (int j = 0; j < kObsBatch; ++j) {
-                                const int q = lane + 64 * (it0 + j);
+                                const int q = lane + 64 * (w + nw * (j0 + j));
                                 if (q < n4) {
+                                    char* dst = obs_s + (q0_off + (uint32_t)(j0 + j) * it_stride);
                                     if constexpr (PAIR) {
                                         v4f v = {va[j].x, va[j].y, vb[j].x, vb[j].y};
-                                        __builtin_nontemporal_store(
-                                            v, reinterpret_cast<v4f*>(obs_s + (uint32_t)q * 16u));
+                                        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst));
                                     } else {
-                                        *reinterpret_cast<float2*>(obs_s + (uint32_t)q * 8u) = va[j];
+                                        *reinterpret_cast<float2*>(dst) = va[j];
                                     }
                                 }
                             }
                         }
                     }
-                    if (n4 > 64 * kFastObsIters)
-                        emit_obs<PAIR>(wl, table, obs_s, 64 * kFastObsIters, n4, lane);
+                    // beyond the register-cached iterations: table-driven
+                    for (int q = lane + 64 * (w + nw * kFastObsIters); q < n4; q += 64 * nw) {
+                        if constexpr (PAIR) {
+                            const uint32_t t = reinterpret_cast<const uint32_t*>(table)[q];
+                            float2 a2 = *reinterpret_cast<const float2*>(sbase + (t & 0xFFFFu));
+                            float2 b2 = *reinterpret_cast<const float2*>(sbase + (t >> 16));
+                            v4f v = {a2.x, a2.y, b2.x, b2.y};
+                            __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(obs_s + (size_t)q * 16));
+                        } else {
+                            *reinterpret_cast<float2*>(obs_s + (size_t)q * 8) =
+                                *reinterpret_cast<const float2*>(sbase + table[q]);
+                        }
+                    }
                     obs_s += obs_stride;
                     wave_lds_sync();
                 }
                 CCX_STAMP(2);                        // observation gather + stores
             }
-            CCX_STAMP_FLUSH(counters, 4);
+            if (w == 0) { CCX_STAMP_FLUSH(counters, 4); }
             return;
         }
     }
@@ -399,6 +430,15 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     const mask_t full = full_mask<GLOG>();
     const mask_t lo_m = low_mask<mask_t>(i);
     const mask_t later_m = ~lo_m & ~(mask_t(1) << i);
+    // occupancy / proposal bit tables of this lane's env: [cells + 1] masks each, the last entry
+    // is a dump slot for lanes that have nothing to publish
+    constexpr uint32_t msz = sizeof(mask_t);
+    const uint32_t cells1 = cells + 1u;
+    const uint32_t g_tab = (g < p.EW) ? (uint32_t)g : 0u;   // unused lanes share env 0's dump slot
+    const uint32_t occ_base = p.off_tiles + (uint32_t)tile_in_block * p.tile_stride + p.off_occ +
+                              g_tab * 2u * cells1 * msz;
+    const uint32_t prp_base = occ_base + cells1 * msz;
+    const uint32_t dump_off = cells * msz;
 
     // ---- state -> registers ------------------------------------------------------------------
     int c = Wp + 1;               // cell index of (0,0)
@@ -504,76 +544,133 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             if (has_order) {
                 uint32_t ok_ = valid ? (uint32_t)*ord_p : (uint32_t)i;  // agent moved i-th
                 ord_p += EN;
-                wl->xch[gbase + (ok_ & (G - 1))] = (uint32_t)i;
+                xch[gbase + (ok_ & (G - 1))] = (uint32_t)i;
                 wave_lds_sync();
-                rank = (int)wl->xch[lane];
+                rank = (int)xch[lane];
                 wave_lds_sync();
             }
 
             stepc += 1;  // collectivecrossing.py:188
 
-            // ---- 1. proposal: target cell + ONE table lookup (collectivecrossing.py:371-376,
-            //         509-534; :565-588 adds nothing to :509-534)
+            // ---- 1. proposal (collectivecrossing.py:371-376, 509-534; :565-588 adds nothing):
+            //         legality is a bit of the CURRENT cell's word; the target's word is fetched
+            //         now and consumed after the move is decided
             const int delta = (int)(int8_t)(uint8_t)(lut >> (a * 8u));
             const int np = c + delta;
             const unsigned long long pci = cinfo[np];
-            const uint32_t plo = (uint32_t)pci, phi = (uint32_t)(pci >> 32);
-            const uint32_t ok = act & (a != 4u) & plo;          // bit0 of plo = VALID
-            const uint32_t curkey = act ? (uint32_t)c : 0x8000u;
-            const uint32_t propkey = (ok & 1u) ? (uint32_t)np : 0xFFFFu;
-            wl->xch[gbase + rank] = curkey | (propkey << 16);
-            wave_lds_sync();
+            const uint32_t ok = act & (((ilo & 0xFu) >> a) & 1u);   // a == 4 (wait/absent): 0
 
-            // ---- 2. this lane now plays move-rank i of its group.  Entries of unused lanes hold
-            //         cur 0x8000 / prop 0xFFFF and can never match a real proposal.
-            const uint32_t myprop = wl->xch[lane] >> 16;
-            mask_t call, pall;
-            if constexpr (GLOG <= 4) {
-                // both 16-bit compares of an entry in 3 VALU ops: xor with (prop,prop), clamp
-                // each half to 0/1 ("differs"), shift into a packed accumulator
-                const uint32_t mp2 = myprop | (myprop << 16);
-                uint32_t acc = 0;
-#pragma unroll
-                for (int k2 = G - 1; k2 >= 0; --k2) {
-                    const uint32_t t = wl->xch[gbase + k2] ^ mp2;
-                    uint32_t ne;   // per 16-bit half: 1 if it differs, 0 if equal
-                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(ne) : "v"(t), "v"(0x00010001u));
-                    acc = (acc << 1) | ne;
-                }
-                const uint32_t eq = ~acc;
-                call = (mask_t)(eq & 0xFFFFu) & full;
-                pall = (mask_t)(eq >> 16) & full;
+            // ---- 2. conflict masks over move ranks: Cm = earlier ranks standing on my target,
+            //         Pm = earlier ranks proposing my target, hard != 0 = cannot move whatever the
+            //         earlier ranks do (no legal proposal, or a later rank still on the target)
+            mask_t Cm, Pm, hard;
+            if constexpr (OCC) {
+                const mask_t mybit = mask_t(1) << rank;
+                const uint32_t o_addr = occ_base + (act ? (uint32_t)c * msz : dump_off);
+                const uint32_t q_addr = prp_base + (ok ? (uint32_t)np * msz : dump_off);
+                const uint32_t r_off = (uint32_t)np * msz;
+                mask_t* const o_p = reinterpret_cast<mask_t*>(smem + o_addr);
+                mask_t* const q_p = reinterpret_cast<mask_t*>(smem + q_addr);
+                __hip_atomic_fetch_or(o_p, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_or(q_p, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                wave_lds_sync();
+                const mask_t occ_t = *reinterpret_cast<const mask_t*>(smem + occ_base + r_off);
+                const mask_t prp_t = *reinterpret_cast<const mask_t*>(smem + prp_base + r_off);
+                wave_lds_sync();
+                *o_p = 0;                      // leave the tables clean for the next step
+                *q_p = 0;
+                // ranks are positions in the move order: rank r's masks are compared in RANK space
+                const mask_t lo_r = has_order ? low_mask<mask_t>(rank) : lo_m;
+                const mask_t later_r = has_order ? (~lo_r & ~mybit) : later_m;
+                Cm = occ_t & lo_r;
+                Pm = prp_t & lo_r;
+                hard = (occ_t & later_r) | (mask_t)(ok ^ 1u);
             } else {
-                call = 0;
-                pall = 0;
+                // all-pairs through the xch tile, indexed by rank: this lane plays move-rank i.
+                // Entries of unused lanes hold cur 0x8000 / prop 0xFFFF and never match.
+                const uint32_t curkey = act ? (uint32_t)c : 0x8000u;
+                const uint32_t propkey = ok ? (uint32_t)np : 0xFFFFu;
+                xch[gbase + rank] = curkey | (propkey << 16);
+                wave_lds_sync();
+                const uint32_t myprop = xch[lane] >> 16;
+                mask_t call, pall;
+                if constexpr (GLOG <= 4) {
+                    // both 16-bit compares of an entry in 3 VALU ops: xor with (prop,prop), clamp
+                    // each half to 0/1 ("differs"), shift into a packed accumulator
+                    const uint32_t mp2 = myprop | (myprop << 16);
+                    uint32_t acc = 0;
 #pragma unroll
-                for (int k2 = 0; k2 < G; ++k2) {
-                    const uint32_t v = wl->xch[gbase + k2];
-                    call |= (mask_t)((v & 0xFFFFu) == myprop) << k2;
-                    pall |= (mask_t)((v >> 16) == myprop) << k2;
+                    for (int k2 = G - 1; k2 >= 0; --k2) {
+                        const uint32_t t = xch[gbase + k2] ^ mp2;
+                        uint32_t ne;   // per 16-bit half: 1 if it differs, 0 if equal
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(ne) : "v"(t), "v"(0x00010001u));
+                        acc = (acc << 1) | ne;
+                    }
+                    const uint32_t eq = ~acc;
+                    call = (mask_t)(eq & 0xFFFFu) & full;
+                    pall = (mask_t)(eq >> 16) & full;
+                } else {
+                    call = 0;
+                    pall = 0;
+#pragma unroll
+                    for (int k2 = 0; k2 < G; ++k2) {
+                        const uint32_t v = xch[gbase + k2];
+                        call |= (mask_t)((v & 0xFFFFu) == myprop) << k2;
+                        pall |= (mask_t)((v >> 16) == myprop) << k2;
+                    }
                 }
+                wave_lds_sync();  // xch is rewritten next step
+                Cm = call & lo_m;
+                Pm = pall & lo_m;
+                hard = (call & later_m) | (mask_t)((myprop + 1u) >> 16);
             }
-            CCX_STAMP(0);   // loop top + proposal + LDS exchange + pair masks
-            const mask_t Cm = call & lo_m, Pm = pall & lo_m;
-            const bool okr = (myprop != 0xFFFFu) && ((call & later_m) == 0);  // later ranks: old cells
+            CCX_STAMP(0);   // loop top + proposal + conflict masks
 
-            // ---- 3. ballot fixed point over "who moved": F(M) is constant for lanes without any
-            //         earlier-rank dependency, so the loop only runs when some lane has one.
-            uint64_t b = __builtin_amdgcn_ballot_w64(okr && (Cm == 0));
-            if (__builtin_amdgcn_ballot_w64(okr && ((Cm | Pm) != 0)) != 0) {
-                for (int it = 1; it < N; ++it) {
-                    const mask_t M = group_bits<GLOG>(b, lane);
-                    const uint64_t b2 = __builtin_amdgcn_ballot_w64(okr && (((M & Pm) | (~M & Cm)) == 0));
-                    if (b2 == b) break;
-                    b = b2;
+            // ---- 3. ballot fixed point over "who moved".  Integer tests keep every ballot a
+            //         single v_cmp; F(M) is constant for lanes without any earlier-rank
+            //         dependency, so the loop only runs when some lane has one.
+            //         OCC: lane = agent, bits = ranks.  !OCC: lane = rank, bits = ranks.
+            uint64_t b = __builtin_amdgcn_ballot_w64((hard | Cm) == 0);
+            const mask_t dep = hard ? mask_t(0) : (Cm | Pm);
+            if (__builtin_amdgcn_ballot_w64(dep != 0) != 0) {
+                if constexpr (OCC) {
+                    if (has_order) {
+                        // ballots are lane(=agent)-indexed here but the masks are rank-indexed:
+                        // resolve through the per-rank view kept in xch (rank -> moved bit)
+                        for (int it = 1; it < N; ++it) {
+                            xch[gbase + rank] = (uint32_t)((b >> lane) & 1ull);
+                            wave_lds_sync();
+                            mask_t M = 0;
+                            for (int k2 = 0; k2 < N; ++k2) M |= (mask_t)xch[gbase + k2] << k2;
+                            wave_lds_sync();
+                            const uint64_t b2 = __builtin_amdgcn_ballot_w64((hard | (M & Pm) | (~M & Cm)) == 0);
+                            if (b2 == b) break;
+                            b = b2;
+                        }
+                    } else {
+                        for (int it = 1; it < N; ++it) {
+                            const mask_t M = group_bits<GLOG>(b, lane);
+                            const uint64_t b2 = __builtin_amdgcn_ballot_w64((hard | (M & Pm) | (~M & Cm)) == 0);
+                            if (b2 == b) break;
+                            b = b2;
+                        }
+                    }
+                } else {
+                    for (int it = 1; it < N; ++it) {
+                        const mask_t M = group_bits<GLOG>(b, lane);
+                        const uint64_t b2 = __builtin_amdgcn_ballot_w64((hard | (M & Pm) | (~M & Cm)) == 0);
+                        if (b2 == b) break;
+                        b = b2;
+                    }
                 }
             }
-            wave_lds_sync();  // xch is rewritten next step
-            const uint32_t moved = (uint32_t)(group_bits<GLOG>(b, lane) >> rank) & 1u;
+            // OCC: the ballot bit of my own lane; !OCC: the bit of the lane playing my rank
+            const uint32_t moved = OCC ? (uint32_t)((b >> lane) & 1ull)
+                                       : ((uint32_t)(group_bits<GLOG>(b, lane) >> rank) & 1u);
             if (moved) {  // collectivecrossing.py:408
                 c = np;
-                ilo = plo;
-                ihi = phi;
+                ilo = (uint32_t)pci;
+                ihi = (uint32_t)(pci >> 32);
             }
             c_moves += moved;
             CCX_STAMP(1);   // ballot fixed point + position update
@@ -604,12 +701,12 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             const bool do_reset = use_pool && valid_env && (ef != 0u);
             if (do_reset) ef |= CCX_K_EF_RESET;
 
-            // ---- 5. hand the step to the writer wave
+            // ---- 5. hand the step to the writer waves
             if constexpr (OUT) {
-                tl->stage[s & 1][lane] = make_uint4(ilo, ihi, af, ef);
+                stage[(s & 1) * 64 + lane] = make_uint4(ilo, ihi, af, ef);
                 CCX_STAMP(2);   // tail
                 lds_barrier();
-                CCX_STAMP(3);   // wait for the writer wave (it may lag one step at most)
+                CCX_STAMP(3);   // wait for the writer waves (they may lag one step at most)
             }
 
             // ---- 6. auto-reset from the pool (reset() :97-150 with host-computed placements)
@@ -725,20 +822,20 @@ __global__ void reset_from_pool_kernel(const KParams p, const KState st,
 // ---------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------
-template <int GLOG, bool PAIR, bool OUT>
+template <int GLOG, bool PAIR, bool OUT, bool OCC>
 static hipError_t launch_rollout_v(const LaunchShape& ls, hipStream_t stream, const KParams& p,
                                    const KState& st, const unsigned long long* cell_info,
                                    const uint8_t* actions, const uint8_t* order, int K,
                                    int auto_reset, const uint8_t* pool, const KOut& out,
                                    unsigned long long* counters) {
     if (ls.lds_bytes > 60 * 1024) {
-        // grids up to 100x100 need more than the default 64 KiB of dynamic LDS (160 KiB per CU)
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<GLOG, PAIR, OUT>),
+        // big grids / many envs per tile need more than the default 64 KiB of dynamic LDS
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<GLOG, PAIR, OUT, OCC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    dim3 grid(ls.num_blocks), block(64 * ls.waves_per_block * (OUT ? 2 : 1));
-    hipLaunchKernelGGL((rollout_kernel<GLOG, PAIR, OUT>), grid, block, ls.lds_bytes, stream, p, st,
+    dim3 grid(ls.num_blocks), block(64 * ls.waves_per_block * (OUT ? 1 + ls.writers : 1));
+    hipLaunchKernelGGL((rollout_kernel<GLOG, PAIR, OUT, OCC>), grid, block, ls.lds_bytes, stream, p, st,
                        cell_info, actions, order, K, auto_reset, pool, out, counters);
     return hipGetLastError();
 }
@@ -751,13 +848,20 @@ static hipError_t launch_rollout_g(const LaunchShape& ls, hipStream_t stream, co
                                    unsigned long long* counters) {
     const bool pair = (p.N % 2) == 0;
     const bool want_out = out.obs || out.reward || out.agent_flags || out.env_flags;
-#define CCX_GO(P_, O_)                                                                           \
-    return launch_rollout_v<GLOG, P_, O_>(ls, stream, p, st, cell_info, actions, order, K,       \
-                                          auto_reset, pool, out, counters)
-    if (pair && want_out) CCX_GO(true, true);
-    if (pair && !want_out) CCX_GO(true, false);
-    if (!pair && want_out) CCX_GO(false, true);
-    CCX_GO(false, false);
+    const int sel = (pair ? 4 : 0) | (want_out ? 2 : 0) | (ls.occ ? 1 : 0);
+#define CCX_GO(P_, O_, C_)                                                                       \
+    return launch_rollout_v<GLOG, P_, O_, C_>(ls, stream, p, st, cell_info, actions, order, K,  \
+                                              auto_reset, pool, out, counters)
+    switch (sel) {
+    case 7: CCX_GO(true, true, true);
+    case 6: CCX_GO(true, true, false);
+    case 5: CCX_GO(true, false, true);
+    case 4: CCX_GO(true, false, false);
+    case 3: CCX_GO(false, true, true);
+    case 2: CCX_GO(false, true, false);
+    case 1: CCX_GO(false, false, true);
+    default: CCX_GO(false, false, false);
+    }
 #undef CCX_GO
 }
 

@@ -19,11 +19,14 @@ from collectivecrossing_amd.batched import BatchedCollectiveCrossing  # noqa: E4
 from collectivecrossing_amd.reset import build_reset_pool  # noqa: E402
 
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+writers = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 E, K, N = 4096, 256, 8
 cfg = c2_config()
 env = BatchedCollectiveCrossing(cfg, E)
 if lanes:
     env.set_launch_shape(lanes, 0)
+if writers:
+    env.set_writers(writers)
 env.set_reset_pool(build_reset_pool(cfg, 0, 1024))
 env.reset_from_pool()
 acts = torch.randint(0, 5, (K, E, N), dtype=torch.uint8, device=env.device)

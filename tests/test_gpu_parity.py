@@ -84,6 +84,56 @@ def test_launch_shapes_do_not_change_results(ccx, name, shape):
     env.close()
 
 
+@pytest.mark.parametrize("name", ["g1_c1_random", "g2_c1_shuffled_absent", "g3_c3_dense_shuffled",
+                                  "g4_c5_all_at_dest_greedy_32_32", "g7_n5_odd", "g7_n50_padded_group"])
+@pytest.mark.parametrize("writers", [1, 2, 3])
+def test_writer_wave_count_does_not_change_results(ccx, name, writers):
+    """1, 2 or 3 writer wavefronts per env tile split the observation stores differently."""
+    g = Golden(name)
+    env = ccx(g.config, g.E)
+    env.set_writers(writers)
+    env.set_state(**g.init_state())
+    res = env.rollout(g["actions"], g["order"])
+    _check_rollout_vs_golden(g, res, env.get_state())
+    env.close()
+
+
+def test_huge_grid_uses_the_all_pairs_fallback_and_big_lds(oracle, ccx):
+    """100x100 grid: the occupancy tables do not fit in LDS (all-pairs path) and the cell table
+    alone needs > 64 KiB of dynamic LDS.  Checked against the oracle, with shuffled move order."""
+    from collectivecrossing_amd import configs as C
+    from collectivecrossing_amd.params import lower_config
+    from collectivecrossing_amd.reset import seeded_positions
+
+    cfg = C.CollectiveCrossingConfig(
+        width=100, height=100, division_y=50, tram_door_left=40, tram_door_right=60, tram_length=100,
+        num_boarding_agents=12, num_exiting_agents=9, exiting_destination_area_y=48,
+        boarding_destination_area_y=52, truncated_config=C.MaxStepsTruncatedConfig(max_steps=40))
+    E, K, N = 37, 50, 21
+    rng = np.random.default_rng(2)
+    actions = rng.integers(0, 5, size=(K, E, N), dtype=np.uint8)
+    order = np.argsort(rng.random((K, E, N)), axis=-1).astype(np.uint8)
+    pos = seeded_positions(cfg, range(E))
+    # crowd everybody next to the door so that conflicts actually happen
+    pos[:, :, 0] = 45 + (np.arange(N) % 7)[None, :]
+    pos[:, :12, 1] = 47 + (np.arange(12) // 7)[None, :]
+    pos[:, 12:, 1] = 51 + (np.arange(9) // 7)[None, :]
+    for o in (None, order):
+        ob = oracle.OracleBatch(lower_config(cfg), E)
+        env = ccx(cfg, E)
+        ob.set_state(x=pos[..., 0], y=pos[..., 1])
+        env.set_state(x=pos[..., 0], y=pos[..., 1])
+        o_obs, o_rew, o_af, o_ef = ob.rollout(actions, o)
+        res = env.rollout(actions, o)
+        np.testing.assert_array_equal(_np(res.agent_flags), o_af)
+        np.testing.assert_array_equal(_np(res.env_flags), o_ef)
+        np.testing.assert_array_equal(_np(res.obs).view(np.uint32), o_obs.view(np.uint32))
+        np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64))
+        assert env.counters() == ob.counters.as_dict()
+        assert env.counters()["moves"] > 0
+        env.close()
+
+
 @pytest.mark.parametrize("name", ROLLOUT_NPZ)
 def test_autoreset_rollout_matches_reference(ccx, name):
     g = Golden(name)
