@@ -172,7 +172,7 @@ def main() -> int:
         env.set_launch_shape(args.lanes, args.wpb)
     if args.writers:
         env.set_writers(args.writers)
-    env.set_reset_pool(build_reset_pool(config, 0, args.pool))
+    env.make_reset_pool(0, args.pool)          # seeds 0..pool-1, placed on the GPU (exact numpy stream)
     env.reset_from_pool()
 
     chunk = max(1, min(args.chunk, args.steps))

@@ -134,8 +134,23 @@ class BatchedCollectiveCrossing:
         return out
 
     # ------------------------------------------------------------------ reset
-    def reset(self, seeds) -> torch.Tensor:
-        """``reset(seed=seeds[e])`` for every env (host placement, exact); returns obs [E,N,L]."""
+    def reset(self, seeds, env_mask=None) -> torch.Tensor:
+        """``reset(seed=seeds[e])`` for every (masked) env ON THE DEVICE (``ccx_reset_seeded``:
+        numpy's SeedSequence -> PCG64 -> bounded-integer stream and the reference's rejection
+        sampling, bit-identical); returns the observations [E,N,L]."""
+        if isinstance(seeds, torch.Tensor):
+            s = seeds.to(device=self.device).view(-1)
+            s = s.view(torch.int64) if s.dtype == torch.uint64 else s.to(torch.int64)
+        else:
+            s = torch.from_numpy(np.asarray(seeds, dtype=np.uint64).reshape(-1).view(np.int64)).to(self.device)
+        if s.numel() != self.num_envs:
+            raise ValueError(f"need {self.num_envs} seeds, got {s.numel()}")
+        m = None if env_mask is None else self._as_dev_u8(env_mask, (self.num_envs,))
+        check(self._lib.ccx_reset_seeded(self._h, _ptr(s.contiguous()), _ptr(m)))
+        return self.observe()
+
+    def reset_host(self, seeds) -> torch.Tensor:
+        """Same placements computed with numpy on the host (``reset.py``) and uploaded."""
         seeds = np.asarray(seeds).reshape(-1)
         if len(seeds) != self.num_envs:
             raise ValueError(f"need {self.num_envs} seeds, got {len(seeds)}")
@@ -157,8 +172,19 @@ class BatchedCollectiveCrossing:
         self._pool = t
         check(self._lib.ccx_set_reset_pool(self._h, _ptr(t), t.shape[0]))
 
-    def make_reset_pool(self, seed0: int, size: int) -> None:
-        self.set_reset_pool(build_reset_pool(self.config, seed0, size))
+    def make_reset_pool(self, seed0: int, size: int, on_device: bool = True) -> None:
+        """Pool of ``reset(seed=seed0 + p)`` placements, p < size; generated on the GPU by default
+        (``ccx_fill_reset_pool_seeded``), or with numpy on the host."""
+        if not on_device:
+            self.set_reset_pool(build_reset_pool(self.config, seed0, size))
+            return
+        t = self._new((size, self.num_agents, 2), torch.uint8)
+        check(self._lib.ccx_fill_reset_pool_seeded(self._h, _ptr(t), size, seed0))
+        self._pool = t
+        check(self._lib.ccx_set_reset_pool(self._h, _ptr(t), size))
+
+    def reset_pool(self) -> torch.Tensor | None:
+        return self._pool
 
     def reset_from_pool(self, env_mask=None) -> None:
         m = None if env_mask is None else self._as_dev_u8(env_mask, (self.num_envs,))

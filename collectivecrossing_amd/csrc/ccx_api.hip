@@ -50,6 +50,7 @@ struct ccx_handle {
     hipStream_t stream = nullptr;
     ccx::KState st{};
     unsigned long long* cell_info = nullptr; // per-cell geometry table (see ccx_kernels.hip: CellInfo)
+    uint8_t* placement_scratch = nullptr;    // u8 [E][N][2] work area of ccx_reset_seeded
     unsigned long long* counters = nullptr;  // 6 x u64 (+ 10 spare words used by diagnostic builds)
     const uint8_t* pool = nullptr;
     int64_t pool_size = 0;
@@ -286,6 +287,7 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     alloc((void**)&h->st.step_count, (size_t)h->E * 4);
     alloc((void**)&h->st.episode, (size_t)h->E * 4);
     alloc((void**)&h->counters, 16 * sizeof(unsigned long long));
+    alloc((void**)&h->placement_scratch, en * 2);
     const std::vector<unsigned long long> cell_tab = build_cell_table(*params);
     alloc((void**)&h->cell_info, cell_tab.size() * sizeof(unsigned long long));
     if (e == hipSuccess)
@@ -325,6 +327,7 @@ void ccx_destroy(ccx_handle* h) {
     (void)hipFree(h->st.episode);
     (void)hipFree(h->counters);
     (void)hipFree(h->cell_info);
+    (void)hipFree(h->placement_scratch);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
     delete h;
@@ -416,6 +419,40 @@ int ccx_reset_from_pool(ccx_handle* h, const uint8_t* env_mask) {
     hipError_t e = ccx::launch_reset_from_pool(h->stream, h->kp, h->st, env_mask, h->pool);
     if (e != hipSuccess) return fail(CCX_EHIP, "reset kernel launch failed: %s", hipGetErrorString(e));
     return CCX_OK;
+}
+
+namespace {
+// counters[7] collects placements that did not converge (the reference would spin forever)
+int finish_placement(ccx_handle* h, const char* what) {
+    unsigned long long fails = 0;
+    CCX_HIP(hipStreamSynchronize(h->stream));
+    CCX_HIP(hipMemcpy(&fails, h->counters + 7, sizeof(fails), hipMemcpyDeviceToHost));
+    if (fails) {
+        CCX_HIP(hipMemset(h->counters + 7, 0, sizeof(fails)));
+        return fail(CCX_EINVAL, "%s: %llu placement(s) found no free cell within %d draws per agent "
+                    "(the reference's rejection sampling would not terminate either)", what, fails, 1 << 16);
+    }
+    return CCX_OK;
+}
+}  // namespace
+
+int ccx_fill_reset_pool_seeded(ccx_handle* h, uint8_t* pool_xy, int64_t pool_size, uint64_t seed0) {
+    if (!h || !pool_xy) return fail(CCX_EINVAL, "NULL argument");
+    if (pool_size < 1 || pool_size >= (1ll << 31)) return fail(CCX_EINVAL, "bad pool_size %lld", (long long)pool_size);
+    CCX_HIP(hipSetDevice(h->device));
+    hipError_t e = ccx::launch_seeded_placement(h->stream, h->kp, (int)pool_size, nullptr, seed0, pool_xy,
+                                                h->st, nullptr, nullptr, 1 << 16, h->counters + 7);
+    if (e != hipSuccess) return fail(CCX_EHIP, "placement kernel launch failed: %s", hipGetErrorString(e));
+    return finish_placement(h, "ccx_fill_reset_pool_seeded");
+}
+
+int ccx_reset_seeded(ccx_handle* h, const uint64_t* seeds, const uint8_t* env_mask) {
+    if (!h || !seeds) return fail(CCX_EINVAL, "NULL argument");
+    CCX_HIP(hipSetDevice(h->device));
+    hipError_t e = ccx::launch_seeded_placement(h->stream, h->kp, h->E, seeds, 0, nullptr, h->st, env_mask,
+                                                h->placement_scratch, 1 << 16, h->counters + 7);
+    if (e != hipSuccess) return fail(CCX_EHIP, "placement kernel launch failed: %s", hipGetErrorString(e));
+    return finish_placement(h, "ccx_reset_seeded");
 }
 
 int ccx_observe(ccx_handle* h, float* obs) {

@@ -174,6 +174,19 @@ int ccx_set_reset_pool(ccx_handle* h, const uint8_t* pool_xy, int64_t pool_size)
  * env's current episode index; clears flags and step_count.  = reset() body :97-150 */
 int ccx_reset_from_pool(ccx_handle* h, const uint8_t* env_mask);
 
+/*
+ * Seeded placement ON THE DEVICE, bit-identical to reset(seed=s) of the reference INCLUDING its
+ * random stream (gymnasium np_random = numpy Generator(PCG64(SeedSequence(s))), rejection sampling
+ * of collectivecrossing.py:100-150).  Synchronous; CCX_EINVAL if a placement finds no free cell
+ * within 65536 draws per agent (the reference would loop forever).
+ *   ccx_fill_reset_pool_seeded: pool_xy[p] = placement of seed seed0 + p, p < pool_size (device
+ *     buffer u8 [pool_size][N][2] of the caller; pass it to ccx_set_reset_pool afterwards).
+ *   ccx_reset_seeded: env e (mask NULL or mask[e] != 0) restarts from reset(seed=seeds[e]):
+ *     positions, active = 1, flags and step_count cleared (seeds: device u64 [E]).
+ */
+int ccx_fill_reset_pool_seeded(ccx_handle* h, uint8_t* pool_xy, int64_t pool_size, uint64_t seed0);
+int ccx_reset_seeded(ccx_handle* h, const uint64_t* seeds, const uint8_t* env_mask);
+
 /* DefaultObservation of the CURRENT state for every agent (what reset() returns, :153-159). */
 int ccx_observe(ccx_handle* h, float* obs /* [E][N][L] */);
 

@@ -66,6 +66,10 @@ def lib() -> C.CDLL:
                                    [C.c_int32, V, V, C.c_int32, V, C.c_int64] + [V] * 4 +
                                    [C.POINTER(CcxCounters)])
         L.ccxo_rollout.restype = None
+        L.ccxo_rng_probe.argtypes = [C.c_uint64, C.c_int, V, V, C.c_int64, C.c_int64, V]
+        L.ccxo_rng_probe.restype = None
+        L.ccxo_seeded_placements.argtypes = [PP, C.c_int32, V, V, C.c_int32]
+        L.ccxo_seeded_placements.restype = C.c_int
         _lib = L
     return _lib
 
@@ -87,6 +91,23 @@ def would_hit_tram_wall(params: CcxParams, x: int, y: int) -> bool:
 
 def reward(params: CcxParams, slot: int, x: int, y: int) -> float:
     return float(lib().ccxo_reward(C.byref(params), slot, x, y))
+
+
+def rng_probe(seed: int, n: int, low: int, high: int):
+    """(raw 64-bit draws, raw 32-bit draws, Generator.integers(low, high) draws) after seeding."""
+    r64, r32, b = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.int64)
+    lib().ccxo_rng_probe(seed, n, r64.ctypes.data, r32.ctypes.data, low, high, b.ctypes.data)
+    return r64, r32, b
+
+
+def seeded_placements(params: CcxParams, seeds, max_tries: int = 1 << 20) -> np.ndarray:
+    """reset(seed=s) placements, u8 [len(seeds), N, 2], from the C restatement of numpy's stream."""
+    seeds = np.ascontiguousarray(seeds, np.uint64)
+    out = np.zeros((len(seeds), params.num_agents, 2), np.uint8)
+    rc = lib().ccxo_seeded_placements(C.byref(params), len(seeds), seeds.ctypes.data, out.ctypes.data, max_tries)
+    if rc != 0:
+        raise RuntimeError("placement did not converge")
+    return out
 
 
 class OracleBatch:

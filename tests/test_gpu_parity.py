@@ -181,6 +181,59 @@ def test_seeded_reset_and_observe_match_reference(ccx):
         env.close()
 
 
+@pytest.mark.parametrize("name", ["g1_c1_random", "g3_c3_dense_simple_distance", "g4_c5_all_at_dest_greedy_32_32",
+                                  "g7_n1_exiting_only", "g7_n5_odd", "g5_sealed_door_greedy", "g7_n50_padded_group"])
+def test_device_seeded_placement_equals_numpy_stream(ccx, name):
+    """ccx_fill_reset_pool_seeded / ccx_reset_seeded (SeedSequence -> PCG64 -> Lemire on the GPU)
+    against numpy itself (reset.py, which is pinned to the reference's placements), 20k seeds
+    including seeds >= 2^32."""
+    import torch
+
+    from collectivecrossing_amd.reset import build_reset_pool, seeded_positions
+
+    g = Golden(name)
+    P = 20000 if g.N <= 8 else 1500
+    env = ccx(g.config, 64)
+    env.make_reset_pool(1000, P)
+    np.testing.assert_array_equal(_np(env.reset_pool()), build_reset_pool(g.config, 1000, P))
+    big = [0, 2**32 - 1, 2**32, 2**32 + 1, 2**40 + 12345, 2**63 + 7, 2**64 - 1, 123456789012345678]
+    seeds = np.array(big + list(range(77, 77 + 64 - len(big))), dtype=np.uint64)
+    obs = _np(env.reset(seeds))
+    st = env.get_state()
+    pos = seeded_positions(g.config, [int(v) for v in seeds])
+    np.testing.assert_array_equal(st["x"], pos[..., 0])
+    np.testing.assert_array_equal(st["y"], pos[..., 1])
+    np.testing.assert_array_equal(obs[:, :, 0], pos[..., 0].astype(np.float32))
+    assert (st["active"] == 1).all() and (st["step_count"] == 0).all()
+    # masked reset leaves the other envs alone
+    env.step(np.full((64, g.N), 4, np.uint8))
+    mask = (np.arange(64) % 3 == 0).astype(np.uint8)
+    env.reset(seeds[::-1].copy(), env_mask=mask)
+    st2 = env.get_state()
+    pos2 = seeded_positions(g.config, [int(v) for v in seeds[::-1]])
+    np.testing.assert_array_equal(st2["x"][mask == 1], pos2[mask == 1][..., 0])
+    np.testing.assert_array_equal(st2["x"][mask == 0], st["x"][mask == 0])
+    assert (st2["step_count"][mask == 1] == 0).all() and (st2["step_count"][mask == 0] == 1).all()
+    env.close()
+
+
+def test_device_placement_reports_impossible_configs(ccx):
+    """More agents than free cells: the reference would spin forever; libccx reports it."""
+    from collectivecrossing_amd import configs as C
+    from collectivecrossing_amd._lib import CcxError
+
+    kw = dict(width=3, height=4, division_y=2, tram_door_left=0, tram_door_right=1, tram_length=2,
+              num_boarding_agents=0, num_exiting_agents=3, exiting_destination_area_y=0,
+              boarding_destination_area_y=3, observation_config=C.DefaultObservationConfig(),
+              reward_config=C.DefaultRewardConfig(), terminated_config=C.IndividualAtDestinationTerminatedConfig(),
+              truncated_config=C.MaxStepsTruncatedConfig(max_steps=5), render_mode=None)
+    cfg = C.CollectiveCrossingConfig.model_construct(**kw)   # tram interior is x=1 only, rows 2..3 -> 1 legal cell
+    env = ccx(cfg, 2)
+    with pytest.raises(CcxError, match="no free cell"):
+        env.reset(np.array([1, 2], dtype=np.uint64))
+    env.close()
+
+
 # ---- against the oracle at sizes the goldens do not reach -------------------------------------
 def _random_case(oracle, ccx, cfg_name, E, K, seed, shuffle, auto_reset, shape=None, p_absent=0.0):
     from collectivecrossing_amd.reset import build_reset_pool, seeded_positions
