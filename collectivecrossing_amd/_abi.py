@@ -94,6 +94,7 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_reset_from_pool": (C.c_int, [_H, C.c_void_p]),
     "ccx_fill_reset_pool_seeded": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_uint64]),
     "ccx_reset_seeded": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "ccx_greedy_actions": (C.c_int, [_H, C.c_void_p]),
     "ccx_observe": (C.c_int, [_H, C.c_void_p]),
     "ccx_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.POINTER(CcxStepOut)]),
     "ccx_rollout": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,

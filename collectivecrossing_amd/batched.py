@@ -190,6 +190,15 @@ class BatchedCollectiveCrossing:
         m = None if env_mask is None else self._as_dev_u8(env_mask, (self.num_envs,))
         check(self._lib.ccx_reset_from_pool(self._h, _ptr(m)))
 
+    # ------------------------------------------------------------------ scripted policy
+    def greedy_actions(self, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Epsilon-0 ``GreedyPolicy`` action of every live agent for the current state, u8 [E, N]
+        (255 for agents that are terminated or truncated) -- ``ccx_greedy_actions``."""
+        if out is None:
+            out = self._new((self.num_envs, self.num_agents), torch.uint8)
+        check(self._lib.ccx_greedy_actions(self._h, _ptr(out)))
+        return out
+
     # ------------------------------------------------------------------ compute
     def observe(self, out: torch.Tensor | None = None) -> torch.Tensor:
         if out is None:

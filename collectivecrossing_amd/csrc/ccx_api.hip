@@ -455,6 +455,14 @@ int ccx_reset_seeded(ccx_handle* h, const uint64_t* seeds, const uint8_t* env_ma
     return finish_placement(h, "ccx_reset_seeded");
 }
 
+int ccx_greedy_actions(ccx_handle* h, uint8_t* actions) {
+    if (!h || !actions) return fail(CCX_EINVAL, "NULL argument");
+    CCX_HIP(hipSetDevice(h->device));
+    hipError_t e = ccx::launch_greedy_actions(h->stream, h->kp, h->st, h->cell_info, actions);
+    if (e != hipSuccess) return fail(CCX_EHIP, "greedy kernel launch failed: %s", hipGetErrorString(e));
+    return CCX_OK;
+}
+
 int ccx_observe(ccx_handle* h, float* obs) {
     if (!h || !obs) return fail(CCX_EINVAL, "NULL argument");
     if (reinterpret_cast<uintptr_t>(obs) & 15u) return fail(CCX_EINVAL, "obs buffer must be 16-byte aligned");

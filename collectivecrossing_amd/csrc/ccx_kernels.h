@@ -71,6 +71,8 @@ hipError_t launch_observe(const LaunchShape& ls, hipStream_t stream, const KPara
 hipError_t launch_reset_from_pool(hipStream_t stream, const KParams& p, const KState& st,
                                   const uint8_t* env_mask, const uint8_t* pool);
 
+hipError_t launch_greedy_actions(hipStream_t stream, const KParams& p, const KState& st,
+                                 const unsigned long long* cell_info, uint8_t* actions);
 hipError_t launch_seeded_placement(hipStream_t stream, const KParams& p, int n, const uint64_t* seeds,
                                    uint64_t seed0, uint8_t* pool_out, const KState& st,
                                    const uint8_t* env_mask, uint8_t* scratch_xy, int max_tries,

@@ -1,0 +1,98 @@
+// ccx_policy.hip -- the reference's GreedyPolicy with epsilon = 0
+// (src/baseline_policies/greedy_policy.py:33-449) for every agent of every env, one thread per
+// (env, agent).  The rule reads only the PRE-step state (the reference computes all actions before
+// env.step, scripts/run_greedy_policy_demo.py:67-109), so agents are independent:
+//   head for the door centre column on the row next to the division line, cross, then run along y
+//   to the destination row (:96-165); if that move is not possible (wall, bounds, a cell held by
+//   another ACTIVE agent: env._is_move_valid, collectivecrossing.py:345-369) take the first legal
+//   move of the preference list (:311-449), else wait.
+// Agents that are terminated or truncated get CCX_ACTION_ABSENT (the reference only asks the policy
+// for env.agents).  Legality of a move w.r.t. walls/bounds is the 4 neighbour bits of the per-cell
+// table (see ccx_kernels.hip); occupancy is an O(N) scan of the env's agents (this kernel is not on
+// the rollout's critical path; the fused rollout uses the LDS occupancy tables instead).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ccx_kernels.h"
+
+namespace ccx {
+
+// (primary action, preference list) of the greedy rule: returns 5 candidate actions packed 4 bits
+// each, candidate 0 first; candidate 4 is always "wait"
+__device__ __forceinline__ uint32_t greedy_candidates(const KParams& p, bool boarding, int cx, int cy) {
+    const int div = p.div, dcx = p.dc;
+    const int dest_y = boarding ? p.bdy : p.edy;
+    const bool before_door = boarding ? (cy < div) : (cy > div);       // greedy_policy.py:118, :139
+    const int door_level = boarding ? div - 1 : div + 1;               // :122, :143
+    const uint32_t fwd = boarding ? 1u : 3u, back = boarding ? 3u : 1u;
+    int dx = 0, dy = 0;
+    if (before_door) {
+        if (cy == door_level) {
+            if (cx == dcx) dy = boarding ? 1 : -1;                     // :126-127, :148-149
+            else dx = (dcx > cx) - (dcx < cx);                         // :129-130
+        } else {
+            dy = (door_level > cy) - (door_level < cy);                // :133-134, :155-156
+        }
+    } else {
+        dy = (dest_y > cy) - (dest_y < cy);                            // :137, :159
+    }
+    const uint32_t primary = dx == 1 ? 0u : dy == 1 ? 1u : dx == -1 ? 2u : dy == -1 ? 3u : 4u;  // :202-234
+    uint32_t p0, p1, p2;
+    if (before_door && cx != dcx) {                                    // :334-349, :396-411
+        p0 = cx < dcx ? 0u : 2u;
+        p1 = fwd;
+        p2 = cx < dcx ? 2u : 0u;
+    } else {                                                           // :350-389, :412-449
+        p0 = fwd;
+        p1 = 0u;
+        p2 = 2u;
+    }
+    return primary | (p0 << 4) | (p1 << 8) | (p2 << 12) | (back << 16) | (4u << 20);
+}
+
+__global__ void greedy_actions_kernel(const KParams p, const KState st,
+                                      const unsigned long long* __restrict__ cell_info,
+                                      uint8_t* __restrict__ actions) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)p.E * p.N;
+    if (t >= total) return;
+    const int env = (int)(t / p.N), i = (int)(t % p.N);
+    if (st.terminated[t] || st.truncated[t]) {
+        actions[t] = (uint8_t)CCX_K_ABSENT;
+        return;
+    }
+    const int cx = st.x[t], cy = st.y[t];
+    const int Wp = p.W + 3;
+    const uint32_t nv = (uint32_t)cell_info[(cy + 1) * Wp + cx + 1] & 0xFu;   // enterable neighbours
+    uint32_t cand = greedy_candidates(p, i < p.Nb, cx, cy);
+    const size_t base = (size_t)env * p.N;
+    uint32_t chosen = 4u;
+    for (int k = 0; k < 6; ++k) {   // candidate 0 = primary, 1..4 preference list, 5 = wait
+        const uint32_t a = k < 5 ? ((cand >> (4 * k)) & 0xFu) : 4u;
+        if (a == 4u) {
+            chosen = 4u;
+            break;
+        }
+        if (!((nv >> a) & 1u)) continue;
+        const int nx = cx + (a == 0u) - (a == 2u), ny = cy + (a == 1u) - (a == 3u);
+        bool taken = false;
+        for (int b = 0; b < p.N; ++b)
+            taken |= (b != i) && st.active[base + b] && st.x[base + b] == nx && st.y[base + b] == ny;
+        if (!taken) {
+            chosen = a;
+            break;
+        }
+    }
+    actions[t] = (uint8_t)chosen;
+}
+
+hipError_t launch_greedy_actions(hipStream_t stream, const KParams& p, const KState& st,
+                                 const unsigned long long* cell_info, uint8_t* actions) {
+    const size_t total = (size_t)p.E * p.N;
+    if (total == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(greedy_actions_kernel, dim3(blocks), dim3(256), 0, stream, p, st, cell_info, actions);
+    return hipGetLastError();
+}
+
+}  // namespace ccx

@@ -187,6 +187,14 @@ int ccx_reset_from_pool(ccx_handle* h, const uint8_t* env_mask);
 int ccx_fill_reset_pool_seeded(ccx_handle* h, uint8_t* pool_xy, int64_t pool_size, uint64_t seed0);
 int ccx_reset_seeded(ccx_handle* h, const uint64_t* seeds, const uint8_t* env_mask);
 
+/*
+ * Batched GreedyPolicy with epsilon = 0 (src/baseline_policies/greedy_policy.py:33-449): the action
+ * the reference's scripted policy picks for every agent of env.agents from the CURRENT state,
+ * actions u8 [E][N]; agents that are terminated or truncated get CCX_ACTION_ABSENT (the rollout loop
+ * of scripts/run_greedy_policy_demo.py:67-109 only asks the policy for env.agents).
+ */
+int ccx_greedy_actions(ccx_handle* h, uint8_t* actions);
+
 /* DefaultObservation of the CURRENT state for every agent (what reset() returns, :153-159). */
 int ccx_observe(ccx_handle* h, float* obs /* [E][N][L] */);
 

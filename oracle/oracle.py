@@ -70,6 +70,8 @@ def lib() -> C.CDLL:
         L.ccxo_rng_probe.restype = None
         L.ccxo_seeded_placements.argtypes = [PP, C.c_int32, V, V, C.c_int32]
         L.ccxo_seeded_placements.restype = C.c_int
+        L.ccxo_greedy_actions.argtypes = [PP, C.c_int32] + [V] * 6
+        L.ccxo_greedy_actions.restype = None
         _lib = L
     return _lib
 
@@ -163,6 +165,14 @@ class OracleBatch:
         lib().ccxo_observe(C.byref(self.params), self.E, _p(self.x, np.int32), _p(self.y, np.int32),
                            _p(self.active, np.uint8), _p(obs, np.float32))
         return obs
+
+    def greedy_actions(self) -> np.ndarray:
+        """Epsilon-0 GreedyPolicy action of every live agent for the current state, u8 [E, N]."""
+        out = np.empty((self.E, self.N), np.uint8)
+        lib().ccxo_greedy_actions(C.byref(self.params), self.E, _p(self.x, np.int32), _p(self.y, np.int32),
+                                  _p(self.active, np.uint8), _p(self.terminated, np.uint8),
+                                  _p(self.truncated, np.uint8), _p(out, np.uint8))
+        return out
 
     def step(self, actions: np.ndarray, order: np.ndarray | None = None, want_obs: bool = True):
         E, N = self.E, self.N

@@ -234,6 +234,44 @@ def test_device_placement_reports_impossible_configs(ccx):
     env.close()
 
 
+@pytest.mark.parametrize("name", [n for n in STEP_NPZ if "greedy" in n])
+def test_greedy_policy_kernel_matches_the_reference_policy(ccx, name):
+    """ccx_greedy_actions against the actions the reference's GreedyPolicy(epsilon=0) emitted."""
+    g = Golden(name)
+    env = ccx(g.config, g.E)
+    env.set_state(**g.init_state())
+    for s in range(g.K):
+        np.testing.assert_array_equal(_np(env.greedy_actions()), g["actions"][s], err_msg=f"{name} step {s}")
+        env.step(g["actions"][s], g["order"][s], want_obs=False)
+    env.close()
+
+
+@pytest.mark.parametrize("cfg_name,E,K", [("g4_c5_all_at_dest_greedy_32_32", 64, 120), ("g1_c1_random", 512, 150),
+                                          ("g3_c3_dense_simple_distance", 128, 130), ("g7_n5_odd", 100, 120)])
+def test_greedy_closed_loop_equals_oracle(oracle, ccx, cfg_name, E, K):
+    """policy -> step -> policy ... on the GPU vs the oracle, from seeded resets (dense door jams)."""
+    from collectivecrossing_amd.reset import seeded_positions
+
+    g = Golden(cfg_name)
+    pos = seeded_positions(g.config, range(9000, 9000 + E))
+    ob = oracle.OracleBatch(g.params, E)
+    env = ccx(g.config, E)
+    ob.set_state(x=pos[..., 0], y=pos[..., 1])
+    env.set_state(x=pos[..., 0], y=pos[..., 1])
+    for s in range(K):
+        a_o = ob.greedy_actions()
+        a_g = env.greedy_actions()
+        np.testing.assert_array_equal(_np(a_g), a_o, err_msg=f"step {s}")
+        o = ob.step(a_o, want_obs=False)
+        r = env.step(a_g, want_obs=False)
+        np.testing.assert_array_equal(_np(r.agent_flags), o[2])
+    st = env.get_state()
+    np.testing.assert_array_equal(st["x"], ob.x)
+    np.testing.assert_array_equal(st["y"], ob.y)
+    assert ob.counters.arrivals > 0
+    env.close()
+
+
 # ---- against the oracle at sizes the goldens do not reach -------------------------------------
 def _random_case(oracle, ccx, cfg_name, E, K, seed, shuffle, auto_reset, shape=None, p_absent=0.0):
     from collectivecrossing_amd.reset import build_reset_pool, seeded_positions
