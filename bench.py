@@ -147,6 +147,9 @@ def main() -> int:
     ap.add_argument("--wpb", type=int, default=0, help="env tiles per workgroup (0=auto)")
     ap.add_argument("--writers", type=int, default=0, help="writer waves per env tile (0=auto)")
     ap.add_argument("--pool", type=int, default=4096, help="reset-pool entries (seeds 0..pool-1)")
+    ap.add_argument("--policy", default="random", choices=["random", "greedy"],
+                    help="random = actions from a device tensor (the bench line); greedy = the "
+                         "reference's GreedyPolicy(epsilon=0) evaluated inside the rollout kernel (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip the observation output")
     args = ap.parse_args()
@@ -190,7 +193,10 @@ def main() -> int:
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            env.rollout(actions[done:done + k], auto_reset=True, out=view)
+            if args.policy == "greedy":
+                env.rollout_greedy(k, auto_reset=True, out=view, want_actions=False)
+            else:
+                env.rollout(actions[done:done + k], auto_reset=True, out=view)
             if events is not None:
                 e1.record()
                 events.append((e0, e1, k))
@@ -243,6 +249,7 @@ def main() -> int:
                                     "max_steps=100, uniform random actions, auto-reset from "
                                     f"{args.pool} reference-exact seeded placements") if args.workload == "c2"
                        else f"{args.workload} (diagnostic, not the bench line)",
+                       "policy": args.policy,
                        "envs_per_gpu": E, "global_envs": total, "agents": N, "obs_len": L,
                        "steps_per_launch": chunk, "launch_shape": env.launch_shape(),
                        "outputs": "full trajectory" + (" (no obs)" if args.no_obs else "")},
@@ -255,7 +262,7 @@ def main() -> int:
                                                     if full else None),
                          "survey_8d_bytes_per_agent_step": survey_unit},
         }
-        if not args.no_cpu_baseline and world == 1 and args.workload == "c2":
+        if not args.no_cpu_baseline and world == 1 and args.workload == "c2" and args.policy == "random":
             line["cpu_baseline"] = cpu_baseline(config, N)
         elif world > 1:
             line["cpu_baseline"] = None

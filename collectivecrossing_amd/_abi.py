@@ -19,6 +19,7 @@ TERMINATED_MODES = {"individual_at_destination": 0, "all_at_destination": 1}
 TRUNCATED_MODES = {"max_steps": 0, "custom": 0}  # truncateds.py:64-95: same arithmetic
 
 ACTION_ABSENT = 255
+POLICY_GREEDY = 1
 
 # agent_flags bits
 AF_TERMINATED, AF_TRUNCATED, AF_LIVE, AF_OBS = 0x01, 0x02, 0x04, 0x08
@@ -99,6 +100,8 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.POINTER(CcxStepOut)]),
     "ccx_rollout": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                               C.POINTER(CcxRolloutOut)]),
+    "ccx_rollout_policy": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CcxRolloutOut),
+                                     C.c_void_p]),
     "ccx_zero_counters": (C.c_int, [_H]),
     "ccx_read_counters": (C.c_int, [_H, C.POINTER(CcxCounters)]),
     "ccx_counters_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p)]),

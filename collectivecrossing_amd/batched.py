@@ -244,6 +244,22 @@ class BatchedCollectiveCrossing:
             check(self._lib.ccx_rollout(self._h, K, _ptr(a), _ptr(o), int(bool(auto_reset)), None))
         return out
 
+    def rollout_greedy(self, num_steps: int, auto_reset: bool = False, out: RolloutResult | None = None,
+                       want_obs: bool = True, actions_out: torch.Tensor | None = None,
+                       want_actions: bool = True):
+        """K fused steps driven by the on-device greedy policy (``ccx_rollout_policy``); returns
+        ``(RolloutResult, actions u8 [K, E, N])``."""
+        K, E, N = int(num_steps), self.num_envs, self.num_agents
+        if out is None:
+            out = self.alloc_rollout(K, want_obs)
+        if actions_out is None and want_actions:
+            actions_out = self._new((K, E, N), torch.uint8)
+        ro = _abi.CcxRolloutOut(_ptr(out.obs).value, _ptr(out.reward).value,
+                                _ptr(out.agent_flags).value, _ptr(out.env_flags).value)
+        check(self._lib.ccx_rollout_policy(self._h, K, _abi.POLICY_GREEDY, int(bool(auto_reset)),
+                                           C.byref(ro), _ptr(actions_out)))
+        return out, actions_out
+
     # ------------------------------------------------------------------ counters / timing / shape
     def zero_counters(self) -> None:
         check(self._lib.ccx_zero_counters(self._h))

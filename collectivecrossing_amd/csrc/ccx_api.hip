@@ -212,7 +212,7 @@ int end_timed(ccx_handle* h) {
 }
 
 int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* order, int auto_reset,
-                const ccx::KOut& out) {
+                const ccx::KOut& out, int policy = 0, uint8_t* actions_out = nullptr) {
     if (out.obs && (reinterpret_cast<uintptr_t>(out.obs) & 15u))
         return fail(CCX_EINVAL, "obs buffer must be 16-byte aligned");
     if (out.reward && (reinterpret_cast<uintptr_t>(out.reward) & 7u))
@@ -221,7 +221,7 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     int rc = begin_timed(h);
     if (rc) return rc;
     hipError_t e = ccx::launch_rollout(h->shape, h->stream, h->kp, h->st, h->cell_info, actions,
-                                       order, K, auto_reset, h->pool, out, h->counters);
+                                       order, K, auto_reset, h->pool, out, h->counters, policy, actions_out);
     if (e != hipSuccess) return fail(CCX_EHIP, "rollout kernel launch failed: %s", hipGetErrorString(e));
     return end_timed(h);
 }
@@ -498,6 +498,26 @@ int ccx_rollout(ccx_handle* h, int32_t num_steps, const uint8_t* actions, const 
         ko.env_flags = out->env_flags;
     }
     return run_rollout(h, num_steps, actions, order, auto_reset ? 1 : 0, ko);
+}
+
+int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t auto_reset,
+                       const ccx_rollout_out* out, uint8_t* actions_out) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if (num_steps < 1) return fail(CCX_EINVAL, "num_steps must be >= 1");
+    if (policy != CCX_POLICY_GREEDY) return fail(CCX_EINVAL, "unknown policy %d", policy);
+    if (!h->shape.occ)
+        return fail(CCX_EINVAL, "policy rollouts need the LDS occupancy tables, which do not fit for this "
+                    "grid / envs-per-wave; drive ccx_step with ccx_greedy_actions instead");
+    if (auto_reset && (!h->pool || h->pool_size <= 0))
+        return fail(CCX_EINVAL, "auto_reset needs a reset pool (ccx_set_reset_pool)");
+    ccx::KOut ko{};
+    if (out) {
+        ko.obs = out->obs;
+        ko.reward = out->reward;
+        ko.agent_flags = out->agent_flags;
+        ko.env_flags = out->env_flags;
+    }
+    return run_rollout(h, num_steps, nullptr, nullptr, auto_reset ? 1 : 0, ko, policy, actions_out);
 }
 
 int ccx_zero_counters(ccx_handle* h) {

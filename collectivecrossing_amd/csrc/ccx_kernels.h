@@ -65,7 +65,7 @@ hipError_t launch_rollout(const LaunchShape& ls, hipStream_t stream, const KPara
                           const KState& st, const unsigned long long* cell_info,
                           const uint8_t* actions, const uint8_t* order, int K,
                           int auto_reset, const uint8_t* pool, const KOut& out,
-                          unsigned long long* counters);
+                          unsigned long long* counters, int policy = 0, uint8_t* actions_out = nullptr);
 hipError_t launch_observe(const LaunchShape& ls, hipStream_t stream, const KParams& p,
                           const KState& st, float* obs);
 hipError_t launch_reset_from_pool(hipStream_t stream, const KParams& p, const KState& st,

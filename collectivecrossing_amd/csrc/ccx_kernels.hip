@@ -44,6 +44,7 @@
 #include <stdint.h>
 
 #include "ccx_kernels.h"
+#include "ccx_greedy.h"
 
 namespace ccx {
 
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(512)
 rollout_kernel(const KParams p, const KState st, const unsigned long long* __restrict__ cell_info,
                const uint8_t* __restrict__ actions, const uint8_t* __restrict__ order, const int K,
                const int auto_reset, const uint8_t* __restrict__ pool, const KOut out,
-               unsigned long long* counters) {
+               unsigned long long* counters, const int policy, uint8_t* __restrict__ actions_out) {
     using mask_t = typename GroupMask<GLOG>::type;
     constexpr int G = 1 << GLOG;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -318,6 +319,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             char* rew_s = small_out ? reinterpret_cast<char*>(out.reward) : nullptr;
             char* af_s = small_out ? reinterpret_cast<char*>(out.agent_flags) : nullptr;
             char* ef_s = small_out ? reinterpret_cast<char*>(out.env_flags) : nullptr;
+            char* act_s = small_out ? reinterpret_cast<char*>(actions_out) : nullptr;   // policy rollouts
             char* obs_s = reinterpret_cast<char*>(out.obs) + (size_t)env0 * N * L * 4;
             const size_t obs_stride = EN * (size_t)L * 4;
             // LDS source addresses of this lane's first kFastObsIters observation stores
@@ -366,7 +368,9 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                         if (rew_s) *reinterpret_cast<double*>(rew_s + rew_off) = r;
                         if (af_s) *reinterpret_cast<uint8_t*>(af_s + af_off) = (uint8_t)af;
                         if (ef_s && i == 0) *reinterpret_cast<uint8_t*>(ef_s + ef_off) = (uint8_t)e.w;
+                        if (act_s) *reinterpret_cast<uint8_t*>(act_s + af_off) = (uint8_t)(af >> 8);
                     }
+                    if (act_s) act_s += EN;
                     if (rew_s) rew_s += EN * 8;
                     if (af_s) af_s += EN;
                     if (ef_s) ef_s += p.E;
@@ -510,7 +514,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
         }
         act_p += (size_t)kActBatch * EN_v;
     };
-    fetch_actions(0);
+    if (!policy) fetch_actions(0);
 
     int s = 0;
     for (int s0 = 0; s0 < K; s0 += kActBatch) {
@@ -529,14 +533,14 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             pnext_pending = false;
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the next burst BEHIND the wait above
-        if (s0 + kActBatch < K) fetch_actions(s0 + kActBatch);
+        if (!policy && s0 + kActBatch < K) fetch_actions(s0 + kActBatch);
         __builtin_amdgcn_sched_barrier(0);
         const int dmax = (K - s0) < kActBatch ? (K - s0) : kActBatch;
 
         uint32_t acur = apk[0];
         for (int d = 0; d < dmax; ++d, ++s) {
             if (d == 8) acur = apk[1];
-            const uint32_t a = acur & 0xFu;
+            uint32_t a = acur & 0xFu;
             acur >>= 4;
 
             // ---- move rank of this agent (dict order of action_dict, collectivecrossing.py:197)
@@ -548,6 +552,29 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                 wave_lds_sync();
                 rank = (int)xch[lane];
                 wave_lds_sync();
+            }
+
+            // ---- 0. policy-driven rollout: the reference's GreedyPolicy(epsilon = 0) picks the action
+            //         from the pre-step state (greedy_policy.py:33-449).  The occupancy bits are
+            //         published first; a direction is free if the current cell's word says the
+            //         neighbour is enterable and no other active agent's bit sits on it.
+            uint32_t a_out = a;
+            if constexpr (OCC) {
+                if (policy) {
+                    const mask_t mybit0 = mask_t(1) << rank;
+                    mask_t* const o_p0 = reinterpret_cast<mask_t*>(smem + occ_base + (act ? (uint32_t)c * msz : dump_off));
+                    __hip_atomic_fetch_or(o_p0, mybit0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    wave_lds_sync();
+                    const mask_t* onb = reinterpret_cast<const mask_t*>(smem + occ_base);
+                    const uint32_t busy = (onb[c + 1] != 0 ? 1u : 0u) | (onb[c + Wp] != 0 ? 2u : 0u) |
+                                          (onb[c - 1] != 0 ? 4u : 0u) | (onb[c - Wp] != 0 ? 8u : 0u);
+                    wave_lds_sync();
+                    const uint32_t cand = greedy_candidates(p, boarding, (int)((ilo >> 16) & 0xFFu), (int)(ilo >> 24));
+                    const uint32_t pick = greedy_pick(cand, ilo & 0xFu & ~busy);
+                    const uint32_t asked = validbit & ~(term | trunc);   // policy is asked for env.agents only
+                    a = asked ? pick : 4u;
+                    a_out = asked ? pick : (uint32_t)CCX_K_ABSENT;
+                }
             }
 
             stepc += 1;  // collectivecrossing.py:188
@@ -571,7 +598,8 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                 const uint32_t r_off = (uint32_t)np * msz;
                 mask_t* const o_p = reinterpret_cast<mask_t*>(smem + o_addr);
                 mask_t* const q_p = reinterpret_cast<mask_t*>(smem + q_addr);
-                __hip_atomic_fetch_or(o_p, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (!policy)   // (already published for the policy)
+                    __hip_atomic_fetch_or(o_p, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __hip_atomic_fetch_or(q_p, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 wave_lds_sync();
                 const mask_t occ_t = *reinterpret_cast<const mask_t*>(smem + occ_base + r_off);
@@ -703,7 +731,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
 
             // ---- 5. hand the step to the writer waves
             if constexpr (OUT) {
-                stage[(s & 1) * 64 + lane] = make_uint4(ilo, ihi, af, ef);
+                stage[(s & 1) * 64 + lane] = make_uint4(ilo, ihi, af | (a_out << 8), ef);
                 CCX_STAMP(2);   // tail
                 lds_barrier();
                 CCX_STAMP(3);   // wait for the writer waves (they may lag one step at most)
@@ -827,7 +855,7 @@ static hipError_t launch_rollout_v(const LaunchShape& ls, hipStream_t stream, co
                                    const KState& st, const unsigned long long* cell_info,
                                    const uint8_t* actions, const uint8_t* order, int K,
                                    int auto_reset, const uint8_t* pool, const KOut& out,
-                                   unsigned long long* counters) {
+                                   unsigned long long* counters, int policy, uint8_t* actions_out) {
     if (ls.lds_bytes > 60 * 1024) {
         // big grids / many envs per tile need more than the default 64 KiB of dynamic LDS
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<GLOG, PAIR, OUT, OCC>),
@@ -836,7 +864,7 @@ static hipError_t launch_rollout_v(const LaunchShape& ls, hipStream_t stream, co
     }
     dim3 grid(ls.num_blocks), block(64 * ls.waves_per_block * (OUT ? 1 + ls.writers : 1));
     hipLaunchKernelGGL((rollout_kernel<GLOG, PAIR, OUT, OCC>), grid, block, ls.lds_bytes, stream, p, st,
-                       cell_info, actions, order, K, auto_reset, pool, out, counters);
+                       cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
     return hipGetLastError();
 }
 
@@ -845,13 +873,13 @@ static hipError_t launch_rollout_g(const LaunchShape& ls, hipStream_t stream, co
                                    const KState& st, const unsigned long long* cell_info,
                                    const uint8_t* actions, const uint8_t* order, int K,
                                    int auto_reset, const uint8_t* pool, const KOut& out,
-                                   unsigned long long* counters) {
+                                   unsigned long long* counters, int policy, uint8_t* actions_out) {
     const bool pair = (p.N % 2) == 0;
-    const bool want_out = out.obs || out.reward || out.agent_flags || out.env_flags;
+    const bool want_out = out.obs || out.reward || out.agent_flags || out.env_flags || actions_out;
     const int sel = (pair ? 4 : 0) | (want_out ? 2 : 0) | (ls.occ ? 1 : 0);
 #define CCX_GO(P_, O_, C_)                                                                       \
     return launch_rollout_v<GLOG, P_, O_, C_>(ls, stream, p, st, cell_info, actions, order, K,  \
-                                              auto_reset, pool, out, counters)
+                                              auto_reset, pool, out, counters, policy, actions_out)
     switch (sel) {
     case 7: CCX_GO(true, true, true);
     case 6: CCX_GO(true, true, false);
@@ -881,15 +909,15 @@ hipError_t launch_rollout(const LaunchShape& ls, hipStream_t stream, const KPara
                           const KState& st, const unsigned long long* cell_info,
                           const uint8_t* actions, const uint8_t* order, int K,
                           int auto_reset, const uint8_t* pool, const KOut& out,
-                          unsigned long long* counters) {
+                          unsigned long long* counters, int policy, uint8_t* actions_out) {
     switch (ls.glog) {
-    case 0: return launch_rollout_g<0>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
-    case 1: return launch_rollout_g<1>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
-    case 2: return launch_rollout_g<2>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
-    case 3: return launch_rollout_g<3>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
-    case 4: return launch_rollout_g<4>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
-    case 5: return launch_rollout_g<5>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
-    case 6: return launch_rollout_g<6>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters);
+    case 0: return launch_rollout_g<0>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
+    case 1: return launch_rollout_g<1>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
+    case 2: return launch_rollout_g<2>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
+    case 3: return launch_rollout_g<3>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
+    case 4: return launch_rollout_g<4>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
+    case 5: return launch_rollout_g<5>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
+    case 6: return launch_rollout_g<6>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
     }
     return hipErrorInvalidValue;
 }

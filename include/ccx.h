@@ -216,6 +216,17 @@ int ccx_step(ccx_handle* h, const uint8_t* actions, const uint8_t* order, const 
 int ccx_rollout(ccx_handle* h, int32_t num_steps, const uint8_t* actions, const uint8_t* order,
                 int32_t auto_reset, const ccx_rollout_out* out);
 
+/*
+ * K fused steps with the actions chosen ON THE DEVICE by a scripted policy from the pre-step state
+ * (policy -> step -> policy ..., the loop of scripts/run_greedy_policy_demo.py:67-109 inside one
+ * launch).  CCX_POLICY_GREEDY = GreedyPolicy with epsilon = 0 (greedy_policy.py:33-449); move order
+ * is slot order (env.agents order).  actions_out (u8 [K][E][N], may be NULL) receives the chosen
+ * actions, CCX_ACTION_ABSENT for agents outside env.agents.
+ */
+enum { CCX_POLICY_GREEDY = 1 };
+int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t auto_reset,
+                       const ccx_rollout_out* out, uint8_t* actions_out);
+
 int ccx_zero_counters(ccx_handle* h);
 int ccx_read_counters(ccx_handle* h, ccx_counters* out_host);   /* synchronous */
 /* device pointer to the 6 u64 counters (for an RCCL all-reduce by the caller) */

@@ -70,6 +70,10 @@ def lib() -> C.CDLL:
         L.ccxo_rng_probe.restype = None
         L.ccxo_seeded_placements.argtypes = [PP, C.c_int32, V, V, C.c_int32]
         L.ccxo_seeded_placements.restype = C.c_int
+        L.ccxo_rollout_greedy.argtypes = ([PP, C.c_int32, C.c_int64, C.c_int64] + [V] * 7 +
+                                          [C.c_int32, V, C.c_int32, V, C.c_int64] + [V] * 4 +
+                                          [C.POINTER(CcxCounters)])
+        L.ccxo_rollout_greedy.restype = None
         L.ccxo_greedy_actions.argtypes = [PP, C.c_int32] + [V] * 6
         L.ccxo_greedy_actions.restype = None
         _lib = L
@@ -213,3 +217,25 @@ class OracleBatch:
                            _p(obs, np.float32), _p(reward_, np.float64), _p(af, np.uint8),
                            _p(ef, np.uint8), C.byref(self.counters))
         return obs, reward_, af, ef
+
+    def rollout_greedy(self, num_steps: int, auto_reset: bool = False, want_obs: bool = True):
+        """K steps of policy -> step with the epsilon-0 greedy policy; returns (actions, obs, reward,
+        agent_flags, env_flags)."""
+        E, N, K = self.E, self.N, int(num_steps)
+        if auto_reset:
+            assert self.pool is not None, "auto_reset needs a reset pool"
+        acts = np.empty((K, E, N), np.uint8)
+        obs = np.empty((K, E, N, self.L), np.float32) if want_obs else None
+        reward_ = np.empty((K, E, N), np.float64)
+        af = np.empty((K, E, N), np.uint8)
+        ef = np.empty((K, E), np.uint8)
+        pool = self.pool
+        lib().ccxo_rollout_greedy(C.byref(self.params), E, self.env_offset, self.total_envs,
+                                  _p(self.x, np.int32), _p(self.y, np.int32), _p(self.active, np.uint8),
+                                  _p(self.terminated, np.uint8), _p(self.truncated, np.uint8),
+                                  _p(self.step_count, np.int32), _p(self.episode, np.int32), K,
+                                  _p(acts, np.uint8), int(bool(auto_reset)), _p(pool, np.uint8),
+                                  0 if pool is None else len(pool), _p(obs, np.float32),
+                                  _p(reward_, np.float64), _p(af, np.uint8), _p(ef, np.uint8),
+                                  C.byref(self.counters))
+        return acts, obs, reward_, af, ef

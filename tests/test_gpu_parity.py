@@ -272,6 +272,47 @@ def test_greedy_closed_loop_equals_oracle(oracle, ccx, cfg_name, E, K):
     env.close()
 
 
+@pytest.mark.parametrize("name", [n for n in STEP_NPZ if "greedy" in n])
+def test_fused_greedy_rollout_reproduces_reference_episodes(ccx, name):
+    """ccx_rollout_policy: the whole policy -> step loop in ONE launch reproduces the episodes the
+    reference produced with GreedyPolicy(epsilon=0) + env.step (actions and every output)."""
+    g = Golden(name)
+    env = ccx(g.config, g.E)
+    env.set_state(**g.init_state())
+    res, acts = env.rollout_greedy(g.K)
+    np.testing.assert_array_equal(_np(acts), g["actions"])
+    _check_rollout_vs_golden(g, res, env.get_state())
+    env.close()
+
+
+@pytest.mark.parametrize("cfg_name,E,K,writers", [("g4_c5_all_at_dest_greedy_32_32", 96, 140, 0),
+                                                  ("g4_c5_all_at_dest_greedy_25_25", 64, 100, 2),
+                                                  ("g1_c1_random", 1024, 260, 0), ("g7_n5_odd", 333, 200, 1),
+                                                  ("g8_rollout_small_all_at_dest", 500, 150, 0)])
+def test_fused_greedy_rollout_with_autoreset_equals_oracle(oracle, ccx, cfg_name, E, K, writers):
+    from collectivecrossing_amd.reset import build_reset_pool
+
+    g = Golden(cfg_name)
+    pool = build_reset_pool(g.config, 4242, 211)
+    ob = oracle.OracleBatch(g.params, E)
+    env = ccx(g.config, E)
+    if writers:
+        env.set_writers(writers)
+    for b in (ob, env):
+        b.set_reset_pool(pool)
+        b.reset_from_pool()
+    o_act, o_obs, o_rew, o_af, o_ef = ob.rollout_greedy(K, auto_reset=True)
+    res, acts = env.rollout_greedy(K, auto_reset=True)
+    np.testing.assert_array_equal(_np(acts), o_act)
+    np.testing.assert_array_equal(_np(res.agent_flags), o_af)
+    np.testing.assert_array_equal(_np(res.env_flags), o_ef)
+    np.testing.assert_array_equal(_np(res.obs).view(np.uint32), o_obs.view(np.uint32))
+    np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64))
+    assert env.counters() == ob.counters.as_dict()
+    assert ob.counters.arrivals > 0
+    env.close()
+
+
 # ---- against the oracle at sizes the goldens do not reach -------------------------------------
 def _random_case(oracle, ccx, cfg_name, E, K, seed, shuffle, auto_reset, shape=None, p_absent=0.0):
     from collectivecrossing_amd.reset import build_reset_pool, seeded_positions
