@@ -219,19 +219,65 @@ class CollectiveCrossingEnv(_Base):
         infos = {aid: {"agent_type": self._type_names[i]} for i, aid in enumerate(self._ids)}
         return observations, infos
 
+    def _alloc_io(self) -> None:
+        """One device buffer + one pinned host buffer for all outputs of a step (a single D2H copy
+        per step), one of each for the inputs."""
+        import ctypes as C
+
+        import torch
+
+        n, L = len(self._ids), 6 + 4 * len(self._ids)
+        a16 = lambda v: (v + 15) & ~15  # noqa: E731
+        o_obs, o_rew = 0, a16(n * L * 4)
+        o_af = o_rew + a16(n * 8)
+        o_ef = o_af + a16(n)
+        total = o_ef + 16
+        dev = self._batch.device
+        self._out_dev = torch.empty(total, dtype=torch.uint8, device=dev)
+        self._out_host = torch.empty(total, dtype=torch.uint8).pin_memory()
+        self._in_dev = torch.empty(2 * n, dtype=torch.uint8, device=dev)
+        self._in_host = torch.empty(2 * n, dtype=torch.uint8).pin_memory()
+        base = self._out_dev.data_ptr()
+        self._step_out = _abi.CcxStepOut(base + o_obs, base + o_rew, base + o_af, base + o_ef)
+        h = self._out_host.numpy()
+        self._h_obs = h[o_obs:o_obs + n * L * 4].view(np.float32).reshape(n, L)
+        self._h_rew = h[o_rew:o_rew + n * 8].view(np.float64)
+        self._h_af = h[o_af:o_af + n]
+        self._h_ef = h[o_ef:o_ef + 1]
+        self._h_in = self._in_host.numpy()
+        self._c_byref = C.byref
+
     def step(self, action_dict):
-        """One tick (collectivecrossing.py:161-261) on the GPU."""
+        """One tick (collectivecrossing.py:161-261) on the GPU: one H2D copy (actions + move
+        order), one ``ccx_step`` launch, one D2H copy (obs + rewards + flag bytes)."""
+        import ctypes as C
+
         actions, order = encode_actions(self._ids, action_dict)
         self._upload()
-        res = self._batch.step(actions[None, :], order[None, :])
-        obs = res.obs.cpu().numpy()[0]
-        reward = res.reward.cpu().numpy()[0]
-        af = res.agent_flags.cpu().numpy()[0]
-        ef = int(res.env_flags.cpu().numpy()[0])
-        before_done = self._mirror.terminated | self._mirror.truncated
-        self._download()
+        if not hasattr(self, "_out_dev"):
+            self._alloc_io()
+        n = len(self._ids)
+        self._h_in[:n] = actions
+        self._h_in[n:] = order
+        self._in_dev.copy_(self._in_host, non_blocking=True)
+        b = self._batch
+        base = self._in_dev.data_ptr()
+        from ._lib import check
+        check(b._lib.ccx_step(b._h, C.c_void_p(base), C.c_void_p(base + n), C.byref(self._step_out)))
+        self._out_host.copy_(self._out_dev, non_blocking=True)
+        b.synchronize()
+        obs, reward, af, ef = self._h_obs, self._h_rew, self._h_af, int(self._h_ef[0])
+        # the new state is fully determined by the outputs: no state read-back
+        m = self._mirror
+        before_done = m.terminated | m.truncated
+        m.x[:] = obs[:, 0].astype(np.int32)
+        m.y[:] = obs[:, 1].astype(np.int32)
+        m.active[:] = (af >> 6) & 1
+        m.terminated |= af & 1
+        m.truncated |= ((af >> 2) & 1) & ((af >> 1) & 1)
+        m.step_count += 1
         out = decode_step(self._ids, obs, reward, af, ef, self._type_names)
-        now_done = self._mirror.terminated | self._mirror.truncated
+        now_done = m.terminated | m.truncated
         self._agents_truncated_or_terminated_this_step = {
             aid for i, aid in enumerate(self._ids) if now_done[i] and not before_done[i]}
         out = self._apply_custom_strategies(out)

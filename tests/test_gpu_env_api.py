@@ -264,3 +264,24 @@ def test_host_reward_strategies_agree_with_the_gpu(Env):
                 env._mirror.dirty = False
                 assert np.float64(host).view(np.uint64) == np.float64(v).view(np.uint64), (a, host, v)
         env.close()
+
+
+def test_mirror_stays_in_sync_with_the_device_state(Env):
+    """step() rebuilds the host mirror from the step outputs (no state read-back): it must equal
+    the device state after every step, through arrivals, truncation and forced writes."""
+    from collectivecrossing_amd.configs import MaxStepsTruncatedConfig
+
+    env = Env(config=_cfg(num_boarding_agents=3, num_exiting_agents=2, truncated_config=MaxStepsTruncatedConfig(max_steps=25)))
+    rng = np.random.default_rng(3)
+    for ep in range(3):
+        env.reset(seed=ep)
+        for t in range(30):
+            env.step({a: int(rng.integers(0, 5)) for a in env.possible_agents if rng.random() < 0.9})
+            st = env._batch.get_state()
+            m = env._mirror
+            for k in ("x", "y", "active", "terminated", "truncated"):
+                np.testing.assert_array_equal(getattr(m, k), st[k][0], err_msg=f"{k} ep {ep} t {t}")
+            assert m.step_count == int(st["step_count"][0])
+            if t == 10:
+                env._agents["exiting_0"].position = np.array([3, 2])
+    env.close()
