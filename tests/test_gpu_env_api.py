@@ -285,3 +285,48 @@ def test_mirror_stays_in_sync_with_the_device_state(Env):
             if t == 10:
                 env._agents["exiting_0"].position = np.array([3, 2])
     env.close()
+
+
+def test_vector_adapter_views_equal_independent_dict_envs(Env):
+    """VectorCollectiveCrossing (one batch, lazy per-env dicts, seeded reset of finished envs on
+    the device) against E independent drop-in envs fed the same dicts."""
+    from collectivecrossing_amd.configs import MaxStepsTruncatedConfig
+    from collectivecrossing_amd.vector import VectorCollectiveCrossing
+
+    cfg = _cfg(num_boarding_agents=3, num_exiting_agents=2, truncated_config=MaxStepsTruncatedConfig(max_steps=12))
+    E = 6
+    vec = VectorCollectiveCrossing(cfg, E)
+    singles = [Env(config=cfg) for _ in range(E)]
+    seeds = np.arange(100, 100 + E, dtype=np.uint64)
+    obs0 = vec.reset(seeds).cpu().numpy()
+    for e, env in enumerate(singles):
+        o, _ = env.reset(seed=int(seeds[e]))
+        for i, a in enumerate(vec.agent_ids):
+            np.testing.assert_array_equal(o[a], obs0[e, i])
+    rng = np.random.default_rng(9)
+    next_seed = 1000
+    for t in range(40):
+        dicts = []
+        for env in singles:
+            ids = list(env.agents)
+            rng.shuffle(ids)
+            dicts.append({a: int(rng.integers(0, 5)) for a in ids})
+        vec.step_dicts(dicts)
+        done = vec.done_mask().cpu().numpy()
+        for e, env in enumerate(singles):
+            o, r, te, tr, inf = env.step(dicts[e])
+            vo, vr, vte, vtr, vinf = vec.view(e)
+            assert r == vr and te == vte and tr == vtr and inf == vinf
+            assert set(o) == set(vo) and all(np.array_equal(o[a], vo[a]) for a in o)
+            assert bool(done[e]) == (te["__all__"] or tr["__all__"])
+        if done.any():
+            new = np.arange(next_seed, next_seed + E, dtype=np.uint64)
+            next_seed += E
+            vec.reset_done(new)
+            for e, env in enumerate(singles):
+                if done[e]:
+                    env.reset(seed=int(new[e]))
+    assert next_seed > 1000
+    vec.close()
+    for env in singles:
+        env.close()
