@@ -20,6 +20,8 @@ TRUNCATED_MODES = {"max_steps": 0, "custom": 0}  # truncateds.py:64-95: same ari
 
 ACTION_ABSENT = 255
 POLICY_GREEDY = 1
+POLICY_WAITING = 2
+POLICIES = {"greedy": POLICY_GREEDY, "waiting": POLICY_WAITING}
 
 # agent_flags bits
 AF_TERMINATED, AF_TRUNCATED, AF_LIVE, AF_OBS = 0x01, 0x02, 0x04, 0x08
@@ -96,6 +98,7 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_fill_reset_pool_seeded": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_uint64]),
     "ccx_reset_seeded": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "ccx_greedy_actions": (C.c_int, [_H, C.c_void_p]),
+    "ccx_policy_actions": (C.c_int, [_H, C.c_int32, C.c_void_p]),
     "ccx_observe": (C.c_int, [_H, C.c_void_p]),
     "ccx_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.POINTER(CcxStepOut)]),
     "ccx_rollout": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,

@@ -191,13 +191,16 @@ class BatchedCollectiveCrossing:
         check(self._lib.ccx_reset_from_pool(self._h, _ptr(m)))
 
     # ------------------------------------------------------------------ scripted policy
-    def greedy_actions(self, out: torch.Tensor | None = None) -> torch.Tensor:
-        """Epsilon-0 ``GreedyPolicy`` action of every live agent for the current state, u8 [E, N]
-        (255 for agents that are terminated or truncated) -- ``ccx_greedy_actions``."""
+    def policy_actions(self, policy: str = "greedy", out: torch.Tensor | None = None) -> torch.Tensor:
+        """Epsilon-0 ``GreedyPolicy`` / ``WaitingPolicy`` action of every live agent for the current
+        state, u8 [E, N] (255 for agents that are terminated or truncated) -- ``ccx_policy_actions``."""
         if out is None:
             out = self._new((self.num_envs, self.num_agents), torch.uint8)
-        check(self._lib.ccx_greedy_actions(self._h, _ptr(out)))
+        check(self._lib.ccx_policy_actions(self._h, _abi.POLICIES[policy], _ptr(out)))
         return out
+
+    def greedy_actions(self, out: torch.Tensor | None = None) -> torch.Tensor:
+        return self.policy_actions("greedy", out)
 
     # ------------------------------------------------------------------ compute
     def observe(self, out: torch.Tensor | None = None) -> torch.Tensor:
@@ -246,9 +249,9 @@ class BatchedCollectiveCrossing:
 
     def rollout_greedy(self, num_steps: int, auto_reset: bool = False, out: RolloutResult | None = None,
                        want_obs: bool = True, actions_out: torch.Tensor | None = None,
-                       want_actions: bool = True):
-        """K fused steps driven by the on-device greedy policy (``ccx_rollout_policy``); returns
-        ``(RolloutResult, actions u8 [K, E, N])``."""
+                       want_actions: bool = True, policy: str = "greedy"):
+        """K fused steps driven by an on-device scripted policy ("greedy" or "waiting",
+        ``ccx_rollout_policy``); returns ``(RolloutResult, actions u8 [K, E, N])``."""
         K, E, N = int(num_steps), self.num_envs, self.num_agents
         if out is None:
             out = self.alloc_rollout(K, want_obs)
@@ -256,7 +259,7 @@ class BatchedCollectiveCrossing:
             actions_out = self._new((K, E, N), torch.uint8)
         ro = _abi.CcxRolloutOut(_ptr(out.obs).value, _ptr(out.reward).value,
                                 _ptr(out.agent_flags).value, _ptr(out.env_flags).value)
-        check(self._lib.ccx_rollout_policy(self._h, K, _abi.POLICY_GREEDY, int(bool(auto_reset)),
+        check(self._lib.ccx_rollout_policy(self._h, K, _abi.POLICIES[policy], int(bool(auto_reset)),
                                            C.byref(ro), _ptr(actions_out)))
         return out, actions_out
 

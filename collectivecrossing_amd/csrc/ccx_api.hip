@@ -455,10 +455,19 @@ int ccx_reset_seeded(ccx_handle* h, const uint64_t* seeds, const uint8_t* env_ma
     return finish_placement(h, "ccx_reset_seeded");
 }
 
+int ccx_policy_actions(ccx_handle* h, int32_t policy, uint8_t* actions) {
+    if (!h || !actions) return fail(CCX_EINVAL, "NULL argument");
+    if (policy != CCX_POLICY_GREEDY && policy != CCX_POLICY_WAITING) return fail(CCX_EINVAL, "unknown policy %d", policy);
+    CCX_HIP(hipSetDevice(h->device));
+    hipError_t e = ccx::launch_greedy_actions(h->stream, h->kp, h->st, h->cell_info, actions, policy);
+    if (e != hipSuccess) return fail(CCX_EHIP, "policy kernel launch failed: %s", hipGetErrorString(e));
+    return CCX_OK;
+}
+
 int ccx_greedy_actions(ccx_handle* h, uint8_t* actions) {
     if (!h || !actions) return fail(CCX_EINVAL, "NULL argument");
     CCX_HIP(hipSetDevice(h->device));
-    hipError_t e = ccx::launch_greedy_actions(h->stream, h->kp, h->st, h->cell_info, actions);
+    hipError_t e = ccx::launch_greedy_actions(h->stream, h->kp, h->st, h->cell_info, actions, CCX_POLICY_GREEDY);
     if (e != hipSuccess) return fail(CCX_EHIP, "greedy kernel launch failed: %s", hipGetErrorString(e));
     return CCX_OK;
 }
@@ -504,7 +513,7 @@ int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t
                        const ccx_rollout_out* out, uint8_t* actions_out) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");
     if (num_steps < 1) return fail(CCX_EINVAL, "num_steps must be >= 1");
-    if (policy != CCX_POLICY_GREEDY) return fail(CCX_EINVAL, "unknown policy %d", policy);
+    if (policy != CCX_POLICY_GREEDY && policy != CCX_POLICY_WAITING) return fail(CCX_EINVAL, "unknown policy %d", policy);
     if (!h->shape.occ)
         return fail(CCX_EINVAL, "policy rollouts need the LDS occupancy tables, which do not fit for this "
                     "grid / envs-per-wave; drive ccx_step with ccx_greedy_actions instead");

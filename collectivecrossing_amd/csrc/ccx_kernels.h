@@ -9,6 +9,7 @@ enum : uint32_t { CCX_K_ABSENT = 255u };
 enum : int { CCX_K_REWARD_DEFAULT = 0, CCX_K_REWARD_SIMPLE_DISTANCE = 1, CCX_K_REWARD_BINARY = 2,
              CCX_K_REWARD_CONSTANT_NEGATIVE = 3 };
 enum : int { CCX_K_TERM_INDIVIDUAL = 0, CCX_K_TERM_ALL = 1 };
+enum : int { CCX_K_POLICY_GREEDY = 1, CCX_K_POLICY_WAITING = 2 };
 enum : uint32_t { CCX_K_EF_ALL_TERM = 1u, CCX_K_EF_ALL_TRUNC = 2u, CCX_K_EF_RESET = 4u };
 
 // kernel parameters (passed by value; lives in SGPRs / the kernarg segment)
@@ -72,7 +73,7 @@ hipError_t launch_reset_from_pool(hipStream_t stream, const KParams& p, const KS
                                   const uint8_t* env_mask, const uint8_t* pool);
 
 hipError_t launch_greedy_actions(hipStream_t stream, const KParams& p, const KState& st,
-                                 const unsigned long long* cell_info, uint8_t* actions);
+                                 const unsigned long long* cell_info, uint8_t* actions, int policy);
 hipError_t launch_seeded_placement(hipStream_t stream, const KParams& p, int n, const uint64_t* seeds,
                                    uint64_t seed0, uint8_t* pool_out, const KState& st,
                                    const uint8_t* env_mask, uint8_t* scratch_xy, int max_tries,

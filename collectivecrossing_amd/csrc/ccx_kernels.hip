@@ -570,8 +570,15 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                                           (onb[c - 1] != 0 ? 4u : 0u) | (onb[c - Wp] != 0 ? 8u : 0u);
                     wave_lds_sync();
                     const uint32_t cand = greedy_candidates(p, boarding, (int)((ilo >> 16) & 0xFFu), (int)(ilo >> 24));
-                    const uint32_t pick = greedy_pick(cand, ilo & 0xFu & ~busy);
+                    uint32_t pick = greedy_pick(cand, ilo & 0xFu & ~busy);
                     const uint32_t asked = validbit & ~(term | trunc);   // policy is asked for env.agents only
+                    if (policy == CCX_K_POLICY_WAITING) {
+                        // waiting_policy.py:74-131: boarding agents outside the tram area wait while
+                        // a live exiting agent is not on its destination row yet
+                        const uint32_t pend = (boarding ? 0u : asked) & (((ilo >> 12) & 1u) ^ 1u);
+                        const mask_t pend_bits = group_bits<GLOG>(__builtin_amdgcn_ballot_w64(pend != 0), lane);
+                        if (boarding && !(ilo & 0x10u) && pend_bits != 0) pick = 4u;
+                    }
                     a = asked ? pick : 4u;
                     a_out = asked ? pick : (uint32_t)CCX_K_ABSENT;
                 }

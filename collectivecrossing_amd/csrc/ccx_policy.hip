@@ -18,9 +18,12 @@
 
 namespace ccx {
 
+// policy: CCX_K_POLICY_GREEDY, or CCX_K_POLICY_WAITING = WaitingPolicy(epsilon = 0)
+// (baseline_policies/waiting_policy.py:33-131): a boarding agent outside the tram area waits while
+// an exiting agent that is neither terminated nor truncated is not on its destination row yet.
 __global__ void greedy_actions_kernel(const KParams p, const KState st,
                                       const unsigned long long* __restrict__ cell_info,
-                                      uint8_t* __restrict__ actions) {
+                                      uint8_t* __restrict__ actions, const int policy) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)p.E * p.N;
     if (t >= total) return;
@@ -31,9 +34,19 @@ __global__ void greedy_actions_kernel(const KParams p, const KState st,
     }
     const int cx = st.x[t], cy = st.y[t];
     const int Wp = p.W + 3;
-    const uint32_t nv = (uint32_t)cell_info[(cy + 1) * Wp + cx + 1] & 0xFu;   // enterable neighbours
+    const uint32_t cw = (uint32_t)cell_info[(cy + 1) * Wp + cx + 1];
+    const uint32_t nv = cw & 0xFu;   // enterable neighbours
     uint32_t cand = greedy_candidates(p, i < p.Nb, cx, cy);
     const size_t base = (size_t)env * p.N;
+    if (policy == CCX_K_POLICY_WAITING && i < p.Nb && !(cw & 0x10u)) {   // waiting_policy.py:92-100
+        bool pending = false;
+        for (int b = p.Nb; b < p.N; ++b)                                  // :119-129
+            pending |= !(st.terminated[base + b] || st.truncated[base + b]) && st.y[base + b] != p.edy;
+        if (pending) {
+            actions[t] = 4;
+            return;
+        }
+    }
     uint32_t chosen = 4u;
     for (int k = 0; k < 6; ++k) {   // candidate 0 = primary, 1..4 preference list, 5 = wait
         const uint32_t a = k < 5 ? ((cand >> (4 * k)) & 0xFu) : 4u;
@@ -55,11 +68,11 @@ __global__ void greedy_actions_kernel(const KParams p, const KState st,
 }
 
 hipError_t launch_greedy_actions(hipStream_t stream, const KParams& p, const KState& st,
-                                 const unsigned long long* cell_info, uint8_t* actions) {
+                                 const unsigned long long* cell_info, uint8_t* actions, int policy) {
     const size_t total = (size_t)p.E * p.N;
     if (total == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(greedy_actions_kernel, dim3(blocks), dim3(256), 0, stream, p, st, cell_info, actions);
+    hipLaunchKernelGGL(greedy_actions_kernel, dim3(blocks), dim3(256), 0, stream, p, st, cell_info, actions, policy);
     return hipGetLastError();
 }
 

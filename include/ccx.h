@@ -46,6 +46,9 @@ enum { CCX_TERM_INDIVIDUAL_AT_DESTINATION = 0, CCX_TERM_ALL_AT_DESTINATION = 1 }
 /* truncateds.py:99-102 ("custom" has the same arithmetic as "max_steps", truncateds.py:64-95) */
 enum { CCX_TRUNC_MAX_STEPS = 0 };
 
+/* scripted policies evaluated on the device (src/baseline_policies/) */
+enum { CCX_POLICY_GREEDY = 1, CCX_POLICY_WAITING = 2 };
+
 /* action codes, actions.py:8-24; CCX_ACTION_ABSENT = agent not in action_dict (it does not move,
  * collectivecrossing.py:197-202 only iterates over the dict's items) */
 enum { CCX_ACTION_RIGHT = 0, CCX_ACTION_UP = 1, CCX_ACTION_LEFT = 2, CCX_ACTION_DOWN = 3,
@@ -194,6 +197,10 @@ int ccx_reset_seeded(ccx_handle* h, const uint64_t* seeds, const uint8_t* env_ma
  * of scripts/run_greedy_policy_demo.py:67-109 only asks the policy for env.agents).
  */
 int ccx_greedy_actions(ccx_handle* h, uint8_t* actions);
+/* same for any scripted policy: CCX_POLICY_GREEDY, or CCX_POLICY_WAITING = WaitingPolicy with
+ * epsilon = 0 (src/baseline_policies/waiting_policy.py:33-131: boarding agents outside the tram area
+ * wait until every exiting agent that is still in env.agents stands on its destination row) */
+int ccx_policy_actions(ccx_handle* h, int32_t policy, uint8_t* actions);
 
 /* DefaultObservation of the CURRENT state for every agent (what reset() returns, :153-159). */
 int ccx_observe(ccx_handle* h, float* obs /* [E][N][L] */);
@@ -223,7 +230,6 @@ int ccx_rollout(ccx_handle* h, int32_t num_steps, const uint8_t* actions, const 
  * is slot order (env.agents order).  actions_out (u8 [K][E][N], may be NULL) receives the chosen
  * actions, CCX_ACTION_ABSENT for agents outside env.agents.
  */
-enum { CCX_POLICY_GREEDY = 1 };
 int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t auto_reset,
                        const ccx_rollout_out* out, uint8_t* actions_out);
 

@@ -70,10 +70,12 @@ def lib() -> C.CDLL:
         L.ccxo_rng_probe.restype = None
         L.ccxo_seeded_placements.argtypes = [PP, C.c_int32, V, V, C.c_int32]
         L.ccxo_seeded_placements.restype = C.c_int
-        L.ccxo_rollout_greedy.argtypes = ([PP, C.c_int32, C.c_int64, C.c_int64] + [V] * 7 +
+        L.ccxo_rollout_policy.argtypes = ([PP, C.c_int32, C.c_int32, C.c_int64, C.c_int64] + [V] * 7 +
                                           [C.c_int32, V, C.c_int32, V, C.c_int64] + [V] * 4 +
                                           [C.POINTER(CcxCounters)])
-        L.ccxo_rollout_greedy.restype = None
+        L.ccxo_rollout_policy.restype = None
+        L.ccxo_policy_actions.argtypes = [PP, C.c_int32, C.c_int32] + [V] * 6
+        L.ccxo_policy_actions.restype = None
         L.ccxo_greedy_actions.argtypes = [PP, C.c_int32] + [V] * 6
         L.ccxo_greedy_actions.restype = None
         _lib = L
@@ -170,13 +172,19 @@ class OracleBatch:
                            _p(self.active, np.uint8), _p(obs, np.float32))
         return obs
 
-    def greedy_actions(self) -> np.ndarray:
-        """Epsilon-0 GreedyPolicy action of every live agent for the current state, u8 [E, N]."""
+    POLICIES = {"greedy": 1, "waiting": 2}
+
+    def policy_actions(self, policy: str = "greedy") -> np.ndarray:
+        """Epsilon-0 GreedyPolicy / WaitingPolicy action of every live agent, u8 [E, N]."""
         out = np.empty((self.E, self.N), np.uint8)
-        lib().ccxo_greedy_actions(C.byref(self.params), self.E, _p(self.x, np.int32), _p(self.y, np.int32),
+        lib().ccxo_policy_actions(C.byref(self.params), self.POLICIES[policy], self.E,
+                                  _p(self.x, np.int32), _p(self.y, np.int32),
                                   _p(self.active, np.uint8), _p(self.terminated, np.uint8),
                                   _p(self.truncated, np.uint8), _p(out, np.uint8))
         return out
+
+    def greedy_actions(self) -> np.ndarray:
+        return self.policy_actions("greedy")
 
     def step(self, actions: np.ndarray, order: np.ndarray | None = None, want_obs: bool = True):
         E, N = self.E, self.N
@@ -218,9 +226,10 @@ class OracleBatch:
                            _p(ef, np.uint8), C.byref(self.counters))
         return obs, reward_, af, ef
 
-    def rollout_greedy(self, num_steps: int, auto_reset: bool = False, want_obs: bool = True):
-        """K steps of policy -> step with the epsilon-0 greedy policy; returns (actions, obs, reward,
-        agent_flags, env_flags)."""
+    def rollout_greedy(self, num_steps: int, auto_reset: bool = False, want_obs: bool = True,
+                       policy: str = "greedy"):
+        """K steps of policy -> step with the epsilon-0 greedy / waiting policy; returns (actions,
+        obs, reward, agent_flags, env_flags)."""
         E, N, K = self.E, self.N, int(num_steps)
         if auto_reset:
             assert self.pool is not None, "auto_reset needs a reset pool"
@@ -230,7 +239,7 @@ class OracleBatch:
         af = np.empty((K, E, N), np.uint8)
         ef = np.empty((K, E), np.uint8)
         pool = self.pool
-        lib().ccxo_rollout_greedy(C.byref(self.params), E, self.env_offset, self.total_envs,
+        lib().ccxo_rollout_policy(C.byref(self.params), self.POLICIES[policy], E, self.env_offset, self.total_envs,
                                   _p(self.x, np.int32), _p(self.y, np.int32), _p(self.active, np.uint8),
                                   _p(self.terminated, np.uint8), _p(self.truncated, np.uint8),
                                   _p(self.step_count, np.int32), _p(self.episode, np.int32), K,

@@ -219,15 +219,16 @@ def run_random(name, cfg, seeds, K, shuffle=False, p_absent=0.0, act_done=True):
     rec.save(name, seeds=np.asarray(seeds, np.int64))
 
 
-def run_greedy(name, cfg, seeds, K):
-    """reset(seed) then the reference's GreedyPolicy(epsilon=0) for live agents in index order."""
-    from baseline_policies import GreedyPolicy
+def run_greedy(name, cfg, seeds, K, policy="greedy"):
+    """reset(seed) then the reference's GreedyPolicy / WaitingPolicy (epsilon=0) for live agents in
+    index order."""
+    from baseline_policies import GreedyPolicy, WaitingPolicy
     rec = Recorder(cfg, len(seeds), K)
     for e, seed in enumerate(seeds):
         env = rec.envs[e]
         obs, _ = env.reset(seed=int(seed))
         rec.snapshot_init(e)
-        pol = GreedyPolicy(randomness_factor=0.0, seed=42)
+        pol = (GreedyPolicy if policy == "greedy" else WaitingPolicy)(randomness_factor=0.0, seed=42)
         for s in range(K):
             acts = {aid: int(pol.get_action(aid, None, env)) for aid in env.agents}
             rec.step(s, e, acts)
@@ -369,12 +370,27 @@ def edge_scenarios():
     return cfg, sc
 
 
+ONLY = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
+
+
+def _selected(fn):
+    """``--only=<prefix>`` regenerates just the fixtures whose name starts with the prefix."""
+    def wrapped(name, *a, **kw):
+        if ONLY and not any(name.startswith(p) for p in ONLY):
+            return
+        return fn(name, *a, **kw)
+    return wrapped
+
+
 def main() -> int:
     if not (REF / "src" / "collectivecrossing").is_dir():
         print(f"reference not found at {REF}: nothing to do (fixtures are committed)")
         return 0
     import_reference()
     replay_reference_goldens()
+    global run_random, run_greedy, run_scenarios, run_rollout
+    run_random, run_greedy, run_scenarios, run_rollout = (_selected(f) for f in (
+        run_random, run_greedy, run_scenarios, run_rollout))
 
     # G1 / G2: BASELINE config-1 geometry, random actions, identity and shuffled move order
     run_random("g1_c1_random", cfg_c1(), seeds=range(0, 24), K=110)
@@ -427,6 +443,12 @@ def main() -> int:
     run_rollout("g8_rollout_small_all_at_dest", cfg_small(
         terminated_config=dict(terminated_function="all_at_destination"),
         truncated_config=dict(truncated_function="max_steps", max_steps=12)), E=8, K=60, P=32, seed0=6000)
+    # G9: WaitingPolicy (epsilon=0): boarding agents outside the tram wait for the exiting ones
+    run_greedy("g9_c1_waiting_policy", cfg_c1(), seeds=range(500, 508), K=110, policy="waiting")
+    run_greedy("g9_small_all_at_dest_waiting_policy", cfg_small(
+        terminated_config=dict(terminated_function="all_at_destination")), seeds=range(510, 518), K=56,
+        policy="waiting")
+    run_greedy("g9_c5_waiting_policy_25_25", cfg_c5(25, 25, max_steps=70), seeds=[520], K=74, policy="waiting")
     return 0
 
 

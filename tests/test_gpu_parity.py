@@ -285,11 +285,29 @@ def test_fused_greedy_rollout_reproduces_reference_episodes(ccx, name):
     env.close()
 
 
+@pytest.mark.parametrize("name", [n for n in STEP_NPZ if "waiting" in n])
+def test_waiting_policy_kernel_and_fused_rollout_match_the_reference(ccx, name):
+    """WaitingPolicy(epsilon=0): stand-alone kernel step by step and the fused rollout against the
+    episodes the reference produced with its own policy."""
+    g = Golden(name)
+    env = ccx(g.config, g.E)
+    env.set_state(**g.init_state())
+    for s in range(g.K):
+        np.testing.assert_array_equal(_np(env.policy_actions("waiting")), g["actions"][s], err_msg=f"{name} step {s}")
+        env.step(g["actions"][s], g["order"][s], want_obs=False)
+    env.set_state(**g.init_state())
+    res, acts = env.rollout_greedy(g.K, policy="waiting")
+    np.testing.assert_array_equal(_np(acts), g["actions"])
+    _check_rollout_vs_golden(g, res, env.get_state())
+    env.close()
+
+
+@pytest.mark.parametrize("policy", ["greedy", "waiting"])
 @pytest.mark.parametrize("cfg_name,E,K,writers", [("g4_c5_all_at_dest_greedy_32_32", 96, 140, 0),
                                                   ("g4_c5_all_at_dest_greedy_25_25", 64, 100, 2),
                                                   ("g1_c1_random", 1024, 260, 0), ("g7_n5_odd", 333, 200, 1),
                                                   ("g8_rollout_small_all_at_dest", 500, 150, 0)])
-def test_fused_greedy_rollout_with_autoreset_equals_oracle(oracle, ccx, cfg_name, E, K, writers):
+def test_fused_greedy_rollout_with_autoreset_equals_oracle(oracle, ccx, cfg_name, E, K, writers, policy):
     from collectivecrossing_amd.reset import build_reset_pool
 
     g = Golden(cfg_name)
@@ -301,15 +319,15 @@ def test_fused_greedy_rollout_with_autoreset_equals_oracle(oracle, ccx, cfg_name
     for b in (ob, env):
         b.set_reset_pool(pool)
         b.reset_from_pool()
-    o_act, o_obs, o_rew, o_af, o_ef = ob.rollout_greedy(K, auto_reset=True)
-    res, acts = env.rollout_greedy(K, auto_reset=True)
+    o_act, o_obs, o_rew, o_af, o_ef = ob.rollout_greedy(K, auto_reset=True, policy=policy)
+    res, acts = env.rollout_greedy(K, auto_reset=True, policy=policy)
     np.testing.assert_array_equal(_np(acts), o_act)
     np.testing.assert_array_equal(_np(res.agent_flags), o_af)
     np.testing.assert_array_equal(_np(res.env_flags), o_ef)
     np.testing.assert_array_equal(_np(res.obs).view(np.uint32), o_obs.view(np.uint32))
     np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64))
     assert env.counters() == ob.counters.as_dict()
-    assert ob.counters.arrivals > 0
+    assert ob.counters.moves > 0
     env.close()
 
 
