@@ -163,6 +163,7 @@ def main() -> int:
         print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: start N>1 with "
               "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`", file=sys.stderr)
         return 2
+    local = local % max(1, torch.cuda.device_count())   # one rank per GPU on a full node
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
