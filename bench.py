@@ -138,11 +138,11 @@ def cpu_baseline(config, n_agents: int, seconds_target: float = 12.0) -> dict:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=250)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the workload's own size")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5_50", "c5_64"])
-    ap.add_argument("--chunk", type=int, default=250, help="env-steps fused per kernel launch")
+    ap.add_argument("--chunk", type=int, default=500, help="env-steps fused per kernel launch")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave carrying agents (0=auto)")
     ap.add_argument("--wpb", type=int, default=0, help="env tiles per workgroup (0=auto)")
     ap.add_argument("--writers", type=int, default=0, help="writer waves per env tile (0=auto)")
@@ -154,6 +154,9 @@ def main() -> int:
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip the observation output")
     args = ap.parse_args()
 
+    if os.environ.get("CCX_DIAG_LIB"):   # diagnostics only: an experimental build of libccx
+        from collectivecrossing_amd import _lib
+        _lib.LIB_PATH = Path(os.environ["CCX_DIAG_LIB"]).resolve()
     from collectivecrossing_amd import sharding
     from collectivecrossing_amd.batched import BatchedCollectiveCrossing
     from collectivecrossing_amd.reset import build_reset_pool

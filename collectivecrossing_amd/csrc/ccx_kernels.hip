@@ -95,6 +95,15 @@ template <int GLOG> __device__ __forceinline__ constexpr typename GroupMask<GLOG
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// streaming 16-byte store of an observation vector (written once, never re-read by the kernel)
+__device__ __forceinline__ void store_obs(v4f v, v4f* dst) {
+#ifdef CCX_PLAIN_STORES
+    *dst = v;
+#else
+    __builtin_nontemporal_store(v, dst);
+#endif
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -175,7 +184,7 @@ __device__ __forceinline__ void emit_obs(const WaveLds* wl, const uint16_t* tabl
             float2 a = *reinterpret_cast<const float2*>(sbase + (t & 0xFFFFu));
             float2 b = *reinterpret_cast<const float2*>(sbase + (t >> 16));
             v4f v = {a.x, a.y, b.x, b.y};
-            __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst + (size_t)q * 16));
+            store_obs(v, reinterpret_cast<v4f*>(dst + (size_t)q * 16));
         } else {
             *reinterpret_cast<float2*>(dst + (size_t)q * 8) =
                 *reinterpret_cast<const float2*>(sbase + table[q]);
@@ -397,7 +406,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                                     char* dst = obs_s + (q0_off + (uint32_t)(j0 + j) * it_stride);
                                     if constexpr (PAIR) {
                                         v4f v = {va[j].x, va[j].y, vb[j].x, vb[j].y};
-                                        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst));
+                                        store_obs(v, reinterpret_cast<v4f*>(dst));
                                     } else {
                                         *reinterpret_cast<float2*>(dst) = va[j];
                                     }
@@ -412,7 +421,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                             float2 a2 = *reinterpret_cast<const float2*>(sbase + (t & 0xFFFFu));
                             float2 b2 = *reinterpret_cast<const float2*>(sbase + (t >> 16));
                             v4f v = {a2.x, a2.y, b2.x, b2.y};
-                            __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(obs_s + (size_t)q * 16));
+                            store_obs(v, reinterpret_cast<v4f*>(obs_s + (size_t)q * 16));
                         } else {
                             *reinterpret_cast<float2*>(obs_s + (size_t)q * 8) =
                                 *reinterpret_cast<const float2*>(sbase + table[q]);
