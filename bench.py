@@ -155,8 +155,11 @@ def main() -> int:
     args = ap.parse_args()
 
     if os.environ.get("CCX_DIAG_LIB"):   # diagnostics only: an experimental build of libccx
-        from collectivecrossing_amd import _lib
+        import ctypes
+        from collectivecrossing_amd import _abi, _lib
         _lib.LIB_PATH = Path(os.environ["CCX_DIAG_LIB"]).resolve()
+        probe = ctypes.CDLL(str(_lib.LIB_PATH))      # older diagnostic builds lack newer symbols
+        _abi.PROTOTYPES = {k: v for k, v in _abi.PROTOTYPES.items() if hasattr(probe, k)}
     from collectivecrossing_amd import sharding
     from collectivecrossing_amd.batched import BatchedCollectiveCrossing
     from collectivecrossing_amd.reset import build_reset_pool
@@ -179,7 +182,7 @@ def main() -> int:
         env.set_launch_shape(args.lanes, args.wpb)
     if args.writers:
         env.set_writers(args.writers)
-    env.make_reset_pool(0, args.pool)          # seeds 0..pool-1, placed on the GPU (exact numpy stream)
+    env.make_reset_pool(0, args.pool, on_device=not os.environ.get("CCX_DIAG_LIB"))  # seeds 0..pool-1
     env.reset_from_pool()
 
     chunk = max(1, min(args.chunk, args.steps))
