@@ -80,6 +80,23 @@ def rollout_bytes_per_agent_step(n_agents: int) -> int:
     return 4 * (6 + 4 * n_agents) + 1 + 8 + 1
 
 
+def write_bandwidth_probe(dev, nbytes: int) -> float:
+    """Achievable pure-WRITE bandwidth of THIS box in GB/s: best of 7 device fills of a buffer as
+    large as one launch's outputs (boxes differ by up to 20 %; SURVEY 8d asks for a measured
+    denominator next to the spec peak)."""
+    buf = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    best = float("inf")
+    for _ in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        buf.fill_(1.0)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        best = min(best, e0.elapsed_time(e1))
+    del buf
+    return nbytes / (best * 1e-3) / 1e9
+
+
 def cpu_baseline(config, n_agents: int, seconds_target: float = 12.0) -> dict:
     """The CPU oracle (a C port of the reference's sequential algorithm) on the host cores, same
     workload (full trajectory outputs), bounded sample."""
@@ -240,8 +257,10 @@ def main() -> int:
         except Exception:
             traffic = None
 
+    probe = write_bandwidth_probe(dev, int(launch_bytes)) if rank == 0 else None
     if rank == 0:
         assert counters["env_steps"] == args.steps * total, counters
+        props = torch.cuda.get_device_properties(dev)
         env_sps = args.steps * total / elapsed
         line = {
             "metric": f"env-steps/sec, random-action rollout, {E} envs x {N} agents per GPU",
@@ -261,10 +280,14 @@ def main() -> int:
                        "steps_per_launch": chunk, "launch_shape": env.launch_shape(),
                        "outputs": "full trajectory" + (" (no obs)" if args.no_obs else "")},
             "counters": counters,
+            "device": {"name": props.name, "compute_units": props.multi_processor_count,
+                       "hbm_GiB": round(props.total_memory / 2**30, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "ccx::rollout_kernel", "kernel_ms_per_launch": kern_ms,
                          "bytes_per_agent_step": bytes_unit, "bytes_per_launch": launch_bytes,
+                         "achievable_write_GBs_this_box": probe,
+                         "frac_of_achievable": achieved / probe if probe else None,
                          "achieved_survey_8d_GBs": (survey_unit * chunk * E * N / (kern_ms * 1e-3) / 1e9
                                                     if full else None),
                          "survey_8d_bytes_per_agent_step": survey_unit},
