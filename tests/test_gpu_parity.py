@@ -431,6 +431,78 @@ def test_full_size_c2_properties(ccx):
     env.close()
 
 
+def test_c4_sharding_is_bit_invariant_at_full_size(ccx):
+    """BASELINE config 4 (32768 envs x 8 agents over 8 GPUs): eight shard handles
+    (env_offset = r*4096, total_envs = 32768), run one after the other on this GPU, reproduce the
+    single 32768-env batch bit for bit -- what makes results identical at 1/2/4/8 GPUs."""
+    import torch
+
+    g = Golden("g1_c1_random")
+    total, world, K, N = 32768, 8, 130, 8
+    per = total // world
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    actions = torch.randint(0, 5, (K, total, N), dtype=torch.uint8, device=dev, generator=gen)
+    whole = ccx(g.config, total)
+    whole.make_reset_pool(77, 5000)
+    whole.reset_from_pool()
+    ref = whole.rollout(actions, auto_reset=True)
+    ref_counters = whole.counters()
+    ref_state = whole.get_state()
+    pool = whole.reset_pool()
+    summed = dict.fromkeys(ref_counters, 0)
+    for r in range(world):
+        shard = ccx(g.config, per, env_offset=r * per, total_envs=total)
+        shard.set_reset_pool(pool)
+        shard.reset_from_pool()
+        out = shard.rollout(actions[:, r * per:(r + 1) * per].contiguous(), auto_reset=True)
+        sl = slice(r * per, (r + 1) * per)
+        assert torch.equal(out.obs.view(torch.int32), ref.obs[:, sl].view(torch.int32))
+        assert torch.equal(out.reward.view(torch.int64), ref.reward[:, sl].view(torch.int64))
+        assert torch.equal(out.agent_flags, ref.agent_flags[:, sl])
+        assert torch.equal(out.env_flags, ref.env_flags[:, sl])
+        st = shard.get_state()
+        for k in ("x", "y", "active", "terminated", "truncated", "step_count", "episode"):
+            np.testing.assert_array_equal(st[k], ref_state[k][sl], err_msg=k)
+        for k, v in shard.counters().items():
+            summed[k] += v
+        shard.close()
+    assert summed == ref_counters and ref_counters["episodes"] >= total
+    whole.close()
+
+
+def test_c5_full_size_greedy_rollout_properties(ccx):
+    """BASELINE config 5 per-GPU share (1024 envs x 64 agents, AllAtDestination, MaxSteps=500,
+    greedy actions inside the kernel): 520 steps with auto-reset.  The door jams (the
+    reference dead-locks and truncates at 500), so every env truncates exactly at step 500."""
+    import torch
+
+    from bench import workload_config
+
+    cfg, E = workload_config("c5_64")
+    env = ccx(cfg, E)
+    env.make_reset_pool(0, 2048)
+    env.reset_from_pool()
+    K, N = 520, 64
+    res, acts = env.rollout_greedy(K, auto_reset=True, want_obs=False)
+    ef = res.env_flags
+    af = res.agent_flags.long()
+    assert bool(((ef[:499] & 3) == 0).all()), "nobody finishes before max_steps"
+    assert bool(((ef[499] & 2) != 0).all()) and bool(((ef[499] & 4) != 0).all()), "all truncate + reset at step 500"
+    assert bool(((af[499] & 2) != 0).all())
+    assert bool((af[500] & 4).bool().all()), "fresh episode: everybody live again"
+    assert bool((acts[:500] != 255).all()) and int(acts.max()) <= 4
+    c = env.counters()
+    assert c["env_steps"] == K * E and c["episodes"] == E and c["arrivals"] > 0 and c["moves"] > 0
+    st = env.get_state()
+    assert (st["step_count"] == 20).all() and (st["episode"] == 1).all()
+    # no two active agents on one cell at the end
+    key = np.where(st["active"] == 1, st["y"] * 128 + st["x"], -1 - np.arange(N)[None, :])
+    srt = np.sort(key, axis=1)
+    assert not (srt[:, 1:] == srt[:, :-1]).any()
+    env.close()
+
+
 def test_errors_are_loud(ccx):
     from collectivecrossing_amd._lib import CcxError
 
