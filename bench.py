@@ -268,7 +268,8 @@ def main() -> int:
             "live_agent_steps_per_sec": counters["live_agent_steps"] / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32 state / f32 obs / f64 reward",
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+            "dtypes": "int32/u8 state and flags, f32 observations (exact integers), f64 rewards (one multiply)",
             "data": "synthetic",
             "config": {"workload": ("C2: 4096 envs x (5 boarding + 3 exiting) per GPU, 12x8 grid, "
                                     "DefaultReward + DefaultObservation, individual_at_destination, "
