@@ -125,6 +125,21 @@ void choose_shape(ccx_handle* h) {
     }
     if (ew < 1) ew = 1;
     if (ew > max_ew) ew = max_ew;
+    if (h->lanes_per_wave == 0) {
+        // Prefer the O(1) occupancy-table conflict masks: carry fewer envs per wave when that makes
+        // the per-env tables fit in LDS (only grids too large even for one env per wave fall back
+        // to the all-pairs compare).
+        auto up = [](size_t v) { return (v + 15u) & ~(size_t)15u; };
+        const size_t cells_ = (size_t)(h->params.width + 3) * (size_t)(h->params.height + 3);
+        const size_t msz_ = (glog == 6) ? 8u : 4u;
+        auto need = [&](int e) {
+            const size_t units_ = (size_t)e * h->N * (3 + 2 * h->N);
+            return up(cells_ * 8u) + up(256u + 2048u + 3u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) +
+                   up((units_ + 2u) * 2u);
+        };
+        if (need(1) <= 96u * 1024u)
+            while (ew > 1 && need(ew) > 96u * 1024u) ew >>= 1;
+    }
     const int tiles = (h->E + ew - 1) / ew;
     // writer waves per tile: enough that a writer handles <= ~6 store iterations per step
     const int units = ew * h->N * (3 + 2 * h->N);

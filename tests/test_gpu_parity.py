@@ -431,6 +431,36 @@ def test_full_size_c2_properties(ccx):
     env.close()
 
 
+def test_mid_size_grid_shrinks_tiles_to_keep_the_occupancy_tables(oracle, ccx):
+    """40x40 grid, 8 agents: eight envs per wave would need 118 KiB of occupancy tables; the
+    library carries fewer envs per wave instead of falling back, so policy rollouts still work."""
+    from collectivecrossing_amd import configs as C
+    from collectivecrossing_amd.params import lower_config
+    from collectivecrossing_amd.reset import build_reset_pool
+
+    cfg = C.CollectiveCrossingConfig(
+        width=40, height=40, division_y=20, tram_door_left=12, tram_door_right=18, tram_length=30,
+        num_boarding_agents=5, num_exiting_agents=3, exiting_destination_area_y=17,
+        boarding_destination_area_y=23, truncated_config=C.MaxStepsTruncatedConfig(max_steps=30),
+        terminated_config=C.AllAtDestinationTerminatedConfig())
+    E, K = 300, 90
+    pool = build_reset_pool(cfg, 5, 97)
+    ob = oracle.OracleBatch(lower_config(cfg), E)
+    env = ccx(cfg, E)
+    assert env.launch_shape()["lanes_per_wave"] < 64
+    for b in (ob, env):
+        b.set_reset_pool(pool)
+        b.reset_from_pool()
+    o_act, o_obs, o_rew, o_af, o_ef = ob.rollout_greedy(K, auto_reset=True)
+    res, acts = env.rollout_greedy(K, auto_reset=True)
+    np.testing.assert_array_equal(_np(acts), o_act)
+    np.testing.assert_array_equal(_np(res.agent_flags), o_af)
+    np.testing.assert_array_equal(_np(res.env_flags), o_ef)
+    np.testing.assert_array_equal(_np(res.obs).view(np.uint32), o_obs.view(np.uint32))
+    assert env.counters() == ob.counters.as_dict() and ob.counters.arrivals > 0
+    env.close()
+
+
 def test_c4_sharding_is_bit_invariant_at_full_size(ccx):
     """BASELINE config 4 (32768 envs x 8 agents over 8 GPUs): eight shard handles
     (env_offset = r*4096, total_envs = 32768), run one after the other on this GPU, reproduce the
