@@ -134,7 +134,7 @@ void choose_shape(ccx_handle* h) {
         const size_t msz_ = (glog == 6) ? 8u : 4u;
         auto need = [&](int e) {
             const size_t units_ = (size_t)e * h->N * (3 + 2 * h->N);
-            return up(cells_ * 8u) + up(256u + 2048u + 3u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) +
+            return up(cells_ * 8u) + up(256u + 2048u + 7u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) +
                    up((units_ + 2u) * 2u);
         };
         if (need(1) <= 96u * 1024u)
@@ -145,7 +145,7 @@ void choose_shape(ccx_handle* h) {
     const int units = ew * h->N * (3 + 2 * h->N);
     const int n4 = (h->N % 2 == 0) ? units / 2 : units;
     int writers = h->writers > 0 ? h->writers : (n4 > 64 * 24 ? 3 : n4 > 64 * 6 ? 2 : 1);
-    if (writers > 3) writers = 3;
+    if (writers > 7) writers = 7;
     int tpb = h->waves_per_block > 0 ? h->waves_per_block : (tiles > 8192 ? 2 : 1);
     while (tpb > 1 && tpb * (1 + writers) > 8) --tpb;   // <= 512 threads per workgroup
     ccx::LaunchShape& s = h->shape;
@@ -590,7 +590,7 @@ int ccx_set_launch_shape(ccx_handle* h, int32_t lanes_per_wave, int32_t waves_pe
 
 int ccx_set_writers(ccx_handle* h, int32_t writers_per_tile) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");
-    if (writers_per_tile < 0 || writers_per_tile > 3) return fail(CCX_EINVAL, "writers_per_tile must be 0..3");
+    if (writers_per_tile < 0 || writers_per_tile > 7) return fail(CCX_EINVAL, "writers_per_tile must be 0..7");
     h->writers = writers_per_tile;
     choose_shape(h);
     return CCX_OK;

@@ -245,7 +245,7 @@ int ccx_last_launch_ms(ccx_handle* h, float* ms);
 /* launch-shape tuning (0 = library default): lanes of each 64-wide wavefront that carry agents
  * (a multiple of the per-env lane group), and wavefronts per workgroup. */
 int ccx_set_launch_shape(ccx_handle* h, int32_t lanes_per_wave, int32_t waves_per_block);
-/* writer wavefronts per env tile (0 = library default, 1..3): the wavefronts that turn a step into
+/* writer wavefronts per env tile (0 = library default, 1..7): the wavefronts that turn a step into
  * reward / flag bytes / observation rows next to the wavefront that simulates it */
 int ccx_set_writers(ccx_handle* h, int32_t writers_per_tile);
 int ccx_get_launch_shape(ccx_handle* h, int32_t* lanes_per_wave, int32_t* waves_per_block,
