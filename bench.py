@@ -80,11 +80,12 @@ def rollout_bytes_per_agent_step(n_agents: int) -> int:
     return 4 * (6 + 4 * n_agents) + 1 + 8 + 1
 
 
-def write_bandwidth_probe(dev, nbytes: int) -> float:
-    """Achievable pure-WRITE bandwidth of THIS box in GB/s: best of 7 device fills of a buffer as
-    large as one launch's outputs (boxes differ by up to 20 %; SURVEY 8d asks for a measured
-    denominator next to the spec peak)."""
-    buf = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+def write_bandwidth_probe(dev, buf: torch.Tensor) -> float:
+    """Achievable pure-WRITE bandwidth of THIS process in GB/s: best of 7 device fills of the very
+    buffer the rollout writes its observations to (the sustained write rate varies by 20-30 %
+    between boxes and allocations; SURVEY 8d asks for a measured denominator next to the peak)."""
+    buf = buf.view(-1)
+    nbytes = buf.numel() * buf.element_size()
     best = float("inf")
     for _ in range(7):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -93,7 +94,6 @@ def write_bandwidth_probe(dev, nbytes: int) -> float:
         e1.record()
         torch.cuda.synchronize(dev)
         best = min(best, e0.elapsed_time(e1))
-    del buf
     return nbytes / (best * 1e-3) / 1e9
 
 
@@ -257,7 +257,7 @@ def main() -> int:
         except Exception:
             traffic = None
 
-    probe = write_bandwidth_probe(dev, int(launch_bytes)) if rank == 0 else None
+    probe = write_bandwidth_probe(dev, traj.obs if traj.obs is not None else traj.reward) if rank == 0 else None
     if rank == 0:
         assert counters["env_steps"] == args.steps * total, counters
         props = torch.cuda.get_device_properties(dev)

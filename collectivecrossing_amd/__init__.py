@@ -19,3 +19,17 @@ def __getattr__(name):  # lazy: importing the configs must not pull in torch
         from .batched import BatchedCollectiveCrossing
         return BatchedCollectiveCrossing
     raise AttributeError(name)
+
+
+def _register_with_gymnasium() -> None:
+    """Same env id as the reference (collectivecrossing/__init__.py:7-10) when gymnasium exists."""
+    try:
+        from gymnasium.envs.registration import register, registry
+    except Exception:
+        return
+    env_id = "collectivecrossing/CollectiveCrossing-v0"
+    if env_id not in registry:
+        register(id=env_id, entry_point="collectivecrossing_amd.env:CollectiveCrossingEnv")
+
+
+_register_with_gymnasium()

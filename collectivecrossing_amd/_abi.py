@@ -113,5 +113,6 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_set_writers": (C.c_int, [_H, C.c_int32]),
     "ccx_get_launch_shape": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ccx_set_stream": (C.c_int, [_H, C.c_void_p]),
     "ccx_synchronize": (C.c_int, [_H]),
 }

@@ -295,6 +295,11 @@ class BatchedCollectiveCrossing:
         return dict(zip(("lanes_per_wave", "waves_per_block", "group_lanes", "num_blocks"),
                         (int(x.value) for x in v)))
 
+    def use_stream(self, stream: "torch.cuda.Stream | None" = None) -> None:
+        """Launch on ``stream`` (default: torch's current stream of the device) from now on."""
+        self._stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        check(self._lib.ccx_set_stream(self._h, C.c_void_p(self._stream.cuda_stream)))
+
     def synchronize(self) -> None:
         check(self._lib.ccx_synchronize(self._h))
 

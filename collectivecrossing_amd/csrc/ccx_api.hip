@@ -606,6 +606,14 @@ int ccx_get_launch_shape(ccx_handle* h, int32_t* lanes_per_wave, int32_t* waves_
     return CCX_OK;
 }
 
+int ccx_set_stream(ccx_handle* h, void* stream) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    CCX_HIP(hipSetDevice(h->device));
+    CCX_HIP(hipStreamSynchronize(h->stream));   // work queued on the old stream finishes first
+    h->stream = reinterpret_cast<hipStream_t>(stream);
+    return CCX_OK;
+}
+
 int ccx_synchronize(ccx_handle* h) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");
     CCX_HIP(hipSetDevice(h->device));

@@ -251,6 +251,8 @@ int ccx_set_writers(ccx_handle* h, int32_t writers_per_tile);
 int ccx_get_launch_shape(ccx_handle* h, int32_t* lanes_per_wave, int32_t* waves_per_block,
                          int32_t* group_lanes, int32_t* num_blocks);
 
+/* rebind the handle to another HIP stream of its device (synchronises the old one first) */
+int ccx_set_stream(ccx_handle* h, void* stream);
 int ccx_synchronize(ccx_handle* h);
 
 #ifdef __cplusplus

@@ -533,6 +533,21 @@ def test_c5_full_size_greedy_rollout_properties(ccx):
     env.close()
 
 
+def test_handle_can_be_moved_to_another_stream(ccx):
+    import torch
+
+    g = Golden("g7_n3_small")
+    env = ccx(g.config, g.E)
+    env.set_state(**g.init_state())
+    side = torch.cuda.Stream(device=env.device)
+    with torch.cuda.stream(side):
+        env.use_stream()
+        res = env.rollout(g["actions"], g["order"])
+    side.synchronize()
+    _check_rollout_vs_golden(g, res, env.get_state())
+    env.close()
+
+
 def test_errors_are_loud(ccx):
     from collectivecrossing_amd._lib import CcxError
 
