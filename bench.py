@@ -169,6 +169,7 @@ def main() -> int:
                          "reference's GreedyPolicy(epsilon=0) evaluated inside the rollout kernel (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip the observation output")
+    ap.add_argument("--only-obs", action="store_true", help="diagnostic: skip reward / flag outputs")
     args = ap.parse_args()
 
     if os.environ.get("CCX_DIAG_LIB"):   # diagnostics only: an experimental build of libccx
@@ -214,6 +215,8 @@ def main() -> int:
             k = min(chunk, nsteps - done)
             view = type(traj)(None if traj.obs is None else traj.obs[:k], traj.reward[:k],
                               traj.agent_flags[:k], traj.env_flags[:k])
+            if args.only_obs:
+                view = type(traj)(view.obs, None, None, None)
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

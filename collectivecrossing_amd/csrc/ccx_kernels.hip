@@ -99,6 +99,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_obs(v4f v, v4f* dst) {
 #ifdef CCX_PLAIN_STORES
     *dst = v;
+#elif defined(CCX_STORE_BITS)   /* diagnostic: explicit cache-policy bits on the store */
+    asm volatile("global_store_dwordx4 %0, %1, off " CCX_STORE_BITS "\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
 #else
     __builtin_nontemporal_store(v, dst);
 #endif
@@ -427,7 +429,9 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                                 *reinterpret_cast<const float2*>(sbase + table[q]);
                         }
                     }
+#ifndef CCX_SAME_SLAB   /* diagnostic: every step overwrites slab 0 (L2-resident) */
                     obs_s += obs_stride;
+#endif
                     wave_lds_sync();
                 }
                 CCX_STAMP(2);                        // observation gather + stores
