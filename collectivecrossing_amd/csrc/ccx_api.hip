@@ -265,6 +265,9 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     int rc = validate_params(params);
     if (rc) return rc;
     if (num_envs < 1) return fail(CCX_EINVAL, "num_envs must be >= 1 (got %d)", num_envs);
+    if ((long long)num_envs * (params->num_boarding + params->num_exiting) >= (1ll << 28))
+        return fail(CCX_EINVAL, "num_envs x agents = %lld exceeds 2^28 (per-lane byte offsets are 32-bit)",
+                    (long long)num_envs * (params->num_boarding + params->num_exiting));
     if (total_envs <= 0) total_envs = num_envs;
     if (env_offset < 0 || env_offset + num_envs > total_envs)
         return fail(CCX_EINVAL, "env_offset %lld + num_envs %d exceeds total_envs %lld",
