@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Quick start on an MI355X: the reference's README example through the drop-in dict API, then the
+same config as a 4096-env batch (random actions, then the on-device greedy policy)."""
+
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+import torch  # noqa: E402
+
+from collectivecrossing_amd import BatchedCollectiveCrossing, CollectiveCrossingConfig, CollectiveCrossingEnv  # noqa: E402
+from collectivecrossing_amd.truncated_configs import MaxStepsTruncatedConfig  # noqa: E402
+
+config = CollectiveCrossingConfig(
+    width=12, height=8, division_y=4, tram_door_left=5, tram_door_right=7, tram_length=9,
+    num_boarding_agents=5, num_exiting_agents=3, exiting_destination_area_y=0,
+    boarding_destination_area_y=8, truncated_config=MaxStepsTruncatedConfig(max_steps=100))
+
+# 1. one env, dict in / dict out -- exactly the reference's API
+env = CollectiveCrossingEnv(config=config)
+obs, infos = env.reset(seed=42)
+obs, rewards, terminateds, truncateds, infos = env.step({a: env.action_spaces[a].sample() for a in env.agents})
+print("dict API:", {a: round(r, 2) for a, r in rewards.items()}, "all done:", terminateds["__all__"])
+env.close()
+
+# 2. 4096 envs in one batch: 500 fused steps per launch, full trajectory on the device
+E, K = 4096, 500
+batch = BatchedCollectiveCrossing(config, E)
+batch.make_reset_pool(seed0=0, size=8192)      # reset(seed) placements, generated on the GPU
+batch.reset_from_pool()
+actions = torch.randint(0, 5, (K, E, batch.num_agents), dtype=torch.uint8, device=batch.device)
+traj = batch.rollout(actions, auto_reset=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+traj = batch.rollout(actions, auto_reset=True, out=traj)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"random rollout: {E * K / dt:.3e} env-steps/s, obs {tuple(traj.obs.shape)}, counters {batch.counters()}")
+
+# 3. the same loop with the reference's GreedyPolicy(epsilon=0) evaluated inside the kernel
+traj, chosen = batch.rollout_greedy(K, auto_reset=True, out=traj)
+print("greedy rollout: mean live reward", float(traj.reward[traj.agent_flags & 4 != 0].mean()),
+      "episodes so far", batch.counters()["episodes"])
+batch.close()
