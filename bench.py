@@ -164,6 +164,7 @@ def main() -> int:
     ap.add_argument("--wpb", type=int, default=0, help="env tiles per workgroup (0=auto)")
     ap.add_argument("--writers", type=int, default=0, help="writer waves per env tile (0=auto)")
     ap.add_argument("--pool", type=int, default=4096, help="reset-pool entries (seeds 0..pool-1)")
+    ap.add_argument("--throttle", type=int, default=0, help="stores a writer keeps in flight (0=auto, -1=off)")
     ap.add_argument("--policy", default="random", choices=["random", "greedy"],
                     help="random = actions from a device tensor (the bench line); greedy = the "
                          "reference's GreedyPolicy(epsilon=0) evaluated inside the rollout kernel (BASELINE configs[4])")
@@ -200,6 +201,8 @@ def main() -> int:
         env.set_launch_shape(args.lanes, args.wpb)
     if args.writers:
         env.set_writers(args.writers)
+    if args.throttle:
+        env.set_store_throttle(args.throttle)
     env.make_reset_pool(0, args.pool, on_device=not os.environ.get("CCX_DIAG_LIB"))  # seeds 0..pool-1
     env.reset_from_pool()
 

@@ -289,11 +289,17 @@ class BatchedCollectiveCrossing:
     def set_writers(self, writers_per_tile: int = 0) -> None:
         check(self._lib.ccx_set_writers(self._h, writers_per_tile))
 
+    def set_store_throttle(self, max_stores_in_flight: int = 0) -> None:
+        check(self._lib.ccx_set_store_throttle(self._h, max_stores_in_flight))
+
     def launch_shape(self) -> dict[str, int]:
         v = [C.c_int32() for _ in range(4)]
         check(self._lib.ccx_get_launch_shape(self._h, *[C.byref(x) for x in v]))
-        return dict(zip(("lanes_per_wave", "waves_per_block", "group_lanes", "num_blocks"),
-                        (int(x.value) for x in v)))
+        w = [C.c_int32() for _ in range(2)]
+        check(self._lib.ccx_get_writer_shape(self._h, *[C.byref(x) for x in w]))
+        return dict(zip(("lanes_per_wave", "waves_per_block", "group_lanes", "num_blocks",
+                         "writers_per_tile", "store_throttle"),
+                        (int(x.value) for x in v + w)))
 
     def use_stream(self, stream: "torch.cuda.Stream | None" = None) -> None:
         """Launch on ``stream`` (default: torch's current stream of the device) from now on."""

@@ -27,7 +27,8 @@ struct KParams {
     uint32_t off_ws, off_occ;            // within a tile: WSlot array, occupancy/proposal tables
     uint32_t occ_words;                  // 32-bit words of one tile's occupancy+proposal tables
     uint32_t off_table;                  // u16 obs address table
-    uint32_t _pad[2];
+    uint32_t _pad;
+    uint32_t writer_vmcnt;               // >0: a writer starts a step only with <= this many of its stores in flight
     double r_dest, r_door, r_area, r_f, r_nogoal, r_pen;
     long long env_offset;                // global index of env 0 (sharding)
     long long pool_size;                 // reset-pool entries (0 = none)
@@ -56,6 +57,7 @@ struct LaunchShape {
     int envs_per_wave;    // EW
     int waves_per_block;  // env tiles per block (each: 1 sim wave + `writers` writer waves)
     int writers;
+    int store_throttle;   // max stores a writer keeps in flight when it starts a step (0 = unlimited)
     int occ;              // 1: occupancy-table conflict masks fit in LDS
     int num_blocks;
     size_t lds_bytes;        // rollout kernel: cell table + per-wave tiles + obs table

@@ -60,6 +60,23 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// wait until at most n vector-memory operations of this wave are in flight (n rounded down to the
+// next available immediate)
+__device__ __forceinline__ void wait_vm_at_most(uint32_t n) {
+    if (n >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (n >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (n >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n >= 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+}
+
 // Workgroup barrier that orders LDS traffic ONLY: __syncthreads() would also wait for vmcnt(0),
 // i.e. drain the writer wave's global stores at every step.
 __device__ __forceinline__ void lds_barrier() {
@@ -435,6 +452,10 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                     wave_lds_sync();
                 }
                 CCX_STAMP(2);                        // observation gather + stores
+                // store throttle: many small tiles oversubscribe the HBM write queues and the drain
+                // rate of the whole chip drops (measured: DESIGN.md 3.6); bounding the stores a
+                // writer keeps in flight keeps the memory side in its efficient regime
+                if (p.writer_vmcnt) wait_vm_at_most(p.writer_vmcnt);
             }
             if (w == 0) { CCX_STAMP_FLUSH(counters, 4); }
             return;

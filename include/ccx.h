@@ -248,6 +248,12 @@ int ccx_set_launch_shape(ccx_handle* h, int32_t lanes_per_wave, int32_t waves_pe
 /* writer wavefronts per env tile (0 = library default, 1..7): the wavefronts that turn a step into
  * reward / flag bytes / observation rows next to the wavefront that simulates it */
 int ccx_set_writers(ccx_handle* h, int32_t writers_per_tile);
+/* store throttle: stores a writer wavefront may still have in flight when it starts the next step
+ * (0 = library default, -1 = unlimited, 1..63).  Many small env tiles oversubscribe the HBM write
+ * queues; bounding the in-flight stores raises the sustained write rate. */
+int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight);
+/* the writers per tile and the store throttle in effect (0 = unlimited) */
+int ccx_get_writer_shape(ccx_handle* h, int32_t* writers_per_tile, int32_t* max_stores_in_flight);
 int ccx_get_launch_shape(ccx_handle* h, int32_t* lanes_per_wave, int32_t* waves_per_block,
                          int32_t* group_lanes, int32_t* num_blocks);
 

@@ -98,6 +98,25 @@ def test_writer_wave_count_does_not_change_results(ccx, name, writers):
     env.close()
 
 
+@pytest.mark.parametrize("name", ["g1_c1_random", "g3_c3_dense_shuffled", "g7_n50_padded_group"])
+@pytest.mark.parametrize("writers,throttle", [(1, 1), (1, 16), (2, 2), (3, 63), (1, -1)])
+def test_store_throttle_does_not_change_results(ccx, name, writers, throttle):
+    """The store throttle only bounds how many observation stores a writer keeps in flight."""
+    g = Golden(name)
+    env = ccx(g.config, g.E)
+    env.set_writers(writers)
+    env.set_store_throttle(throttle)
+    shape = env.launch_shape()
+    assert shape["writers_per_tile"] == writers
+    assert shape["store_throttle"] == (0 if throttle < 0 else throttle)
+    env.set_state(**g.init_state())
+    res = env.rollout(g["actions"], g["order"])
+    _check_rollout_vs_golden(g, res, env.get_state())
+    with pytest.raises(Exception):
+        env.set_store_throttle(64)
+    env.close()
+
+
 def test_huge_grid_uses_the_all_pairs_fallback_and_big_lds(oracle, ccx):
     """100x100 grid: the occupancy tables do not fit in LDS (all-pairs path) and the cell table
     alone needs > 64 KiB of dynamic LDS.  Checked against the oracle, with shuffled move order."""
