@@ -155,8 +155,8 @@ def cpu_baseline(config, n_agents: int, seconds_target: float = 12.0) -> dict:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the workload's own size")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5_50", "c5_64"])
     ap.add_argument("--chunk", type=int, default=500, help="env-steps fused per kernel launch")
@@ -208,7 +208,8 @@ def main() -> int:
 
     chunk = max(1, min(args.chunk, args.steps))
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    n_act = max(args.steps, args.warmup, 1)
+    # the action stream is `n_act` steps long (a multiple of the launch size) and wraps around
+    n_act = max(chunk, min(max(args.steps, args.warmup, 1), 4000) // chunk * chunk)
     actions = torch.randint(0, 5, (n_act, E, N), dtype=torch.uint8, device=dev, generator=gen)
     traj = env.alloc_rollout(chunk, want_obs=not args.no_obs)
 
@@ -226,7 +227,8 @@ def main() -> int:
             if args.policy == "greedy":
                 env.rollout_greedy(k, auto_reset=True, out=view, want_actions=False)
             else:
-                env.rollout(actions[done:done + k], auto_reset=True, out=view)
+                a0 = done % n_act
+                env.rollout(actions[a0:a0 + k], auto_reset=True, out=view)
             if events is not None:
                 e1.record()
                 events.append((e0, e1, k))
