@@ -115,6 +115,7 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_get_writer_shape": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccx_get_launch_shape": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ccx_host_device_pointer": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_void_p)]),
     "ccx_set_stream": (C.c_int, [_H, C.c_void_p]),
     "ccx_synchronize": (C.c_int, [_H]),
 }

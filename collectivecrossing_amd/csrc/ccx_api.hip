@@ -644,6 +644,21 @@ int ccx_get_writer_shape(ccx_handle* h, int32_t* writers_per_tile, int32_t* max_
     return CCX_OK;
 }
 
+int ccx_host_device_pointer(ccx_handle* h, void* pinned_host, void** device_ptr) {
+    if (!h || !pinned_host || !device_ptr) return fail(CCX_EINVAL, "NULL argument");
+    CCX_HIP(hipSetDevice(h->device));
+    hipPointerAttribute_t attr{};
+    hipError_t e = hipPointerGetAttributes(&attr, pinned_host);
+    if (e != hipSuccess || attr.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return fail(CCX_EINVAL, "pointer is not page-locked host memory registered with HIP");
+    }
+    void* d = nullptr;
+    CCX_HIP(hipHostGetDevicePointer(&d, pinned_host, 0));
+    *device_ptr = d;
+    return CCX_OK;
+}
+
 int ccx_set_stream(ccx_handle* h, void* stream) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");
     CCX_HIP(hipSetDevice(h->device));

@@ -18,6 +18,8 @@ Deliberate differences (documented in DESIGN.md):
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import _abi
@@ -38,22 +40,54 @@ except Exception:
 
 
 class _Mirror:
-    """Host copy of the one-env SoA state; ``dirty`` = must be uploaded before the next launch."""
+    """Host copy of the one-env SoA state; ``dirty`` = must be uploaded before the next launch.
+
+    ``step()`` does not update the arrays eagerly: it parks the step's outputs with ``defer`` and the
+    arrays are brought up to date on first access (the ``env._agents[...]`` views, ``_upload``, the
+    helper predicates) -- a plain rollout loop never pays for them.  ``version`` counts external
+    writes so the env knows when its own per-step flag lists are out of date.
+    """
 
     FIELDS = ("x", "y", "active", "terminated", "truncated")
 
     def __init__(self, n: int):
-        self.x = np.zeros(n, np.int32)
-        self.y = np.zeros(n, np.int32)
-        self.active = np.ones(n, np.uint8)
-        self.terminated = np.zeros(n, np.uint8)
-        self.truncated = np.zeros(n, np.uint8)
+        self._arr = {"x": np.zeros(n, np.int32), "y": np.zeros(n, np.int32), "active": np.ones(n, np.uint8),
+                     "terminated": np.zeros(n, np.uint8), "truncated": np.zeros(n, np.uint8)}
+        self._pending = None
         self.step_count = 0
         self.dirty = True
+        self.version = 0
+
+    def defer(self, obs: np.ndarray, active: list, terminated: list, truncated: list) -> None:
+        """Park the latest post-step state: obs columns 0/1 are x/y, the lists are cumulative flags."""
+        self._pending = (obs, active, terminated, truncated)
+
+    def _sync(self) -> None:
+        obs, active, terminated, truncated = self._pending
+        self._pending = None
+        a = self._arr
+        xy = obs[:, :2].astype(np.int32)
+        a["x"][:], a["y"][:] = xy[:, 0], xy[:, 1]
+        a["active"][:], a["terminated"][:], a["truncated"][:] = active, terminated, truncated
+
+    def _field(name):  # noqa: N805
+        def get(self) -> np.ndarray:
+            if self._pending is not None:
+                self._sync()
+            return self._arr[name]
+        return property(get)
+
+    x, y, active = _field("x"), _field("y"), _field("active")
+    terminated, truncated = _field("terminated"), _field("truncated")
+    del _field
+
+    def touch(self) -> None:
+        self.version += 1
 
     def write(self, name: str, index: int, value: int) -> None:
         getattr(self, name)[index] = value
         self.dirty = True
+        self.version += 1
 
 
 def decode_step(ids, obs, reward, agent_flags, env_flag, agent_types):
@@ -62,44 +96,53 @@ def decode_step(ids, obs, reward, agent_flags, env_flag, agent_types):
     Pure function (the CPU test-suite exercises it without a GPU):
     ``rewards`` / ``truncateds`` only hold agents that were live before the step (CCX_AF_LIVE),
     ``terminateds`` holds everybody, ``observations`` / ``infos`` hold CCX_AF_OBS agents, and both
-    flag dicts get ``"__all__"``.
+    flag dicts get ``"__all__"``.  The observation rows are views of ONE fresh copy of ``obs``.
     """
     observations, rewards, terminateds, truncateds, infos = {}, {}, {}, {}, {}
+    flags = agent_flags.tolist() if hasattr(agent_flags, "tolist") else [int(f) for f in agent_flags]
+    rew = reward.tolist() if hasattr(reward, "tolist") else [float(r) for r in reward]
+    rows = np.array(obs, dtype=np.float32)
     for i, aid in enumerate(ids):
-        f = int(agent_flags[i])
-        terminateds[aid] = bool(f & _abi.AF_TERMINATED)
-        if f & _abi.AF_LIVE:
-            rewards[aid] = float(reward[i])
-            truncateds[aid] = bool(f & _abi.AF_TRUNCATED)
-        if f & _abi.AF_OBS:
-            observations[aid] = np.array(obs[i], dtype=np.float32)
-            infos[aid] = {"agent_type": agent_types[i], "in_tram_area": bool(f & _abi.AF_IN_TRAM_AREA),
-                          "at_door": bool(f & _abi.AF_AT_DOOR), "active": bool(f & _abi.AF_ACTIVE),
-                          "at_destination": bool(f & _abi.AF_AT_DEST)}
+        f = flags[i]
+        terminateds[aid] = (f & 1) != 0                     # CCX_AF_TERMINATED
+        if f & 4:                                           # CCX_AF_LIVE
+            rewards[aid] = rew[i]
+            truncateds[aid] = (f & 2) != 0                  # CCX_AF_TRUNCATED
+        if f & 8:                                           # CCX_AF_OBS
+            observations[aid] = rows[i]
+            infos[aid] = {"agent_type": agent_types[i], "in_tram_area": (f & 0x10) != 0,
+                          "at_door": (f & 0x20) != 0, "active": (f & 0x40) != 0,
+                          "at_destination": (f & 0x80) != 0}
     terminateds["__all__"] = bool(env_flag & _abi.EF_ALL_TERMINATED)
     truncateds["__all__"] = bool(env_flag & _abi.EF_ALL_TRUNCATED)
     return observations, rewards, terminateds, truncateds, infos
 
 
-def encode_actions(ids, action_dict):
-    """``action_dict`` -> (actions u8 [N] with 255 = absent, move order u8 [N]); raises the
-    reference's ``ValueError``s (collectivecrossing.py:685-711), agent check before action check."""
-    slot = {aid: i for i, aid in enumerate(ids)}
+def _encode_lists(ids, slot, action_dict):
     n = len(ids)
-    actions = np.full(n, _abi.ACTION_ABSENT, np.uint8)
+    actions = [_abi.ACTION_ABSENT] * n
     order = []
     for aid, action in action_dict.items():
-        if aid not in slot:
+        i = slot.get(aid)
+        if i is None:
             raise ValueError(f"Unknown agent ID: {aid} in action_dict. The action_dict keys must be a "
                              f"subset of the agents. Current agents: {dict.fromkeys(ids).keys()}")
         if action not in ACTION_TO_DIRECTION:
             raise ValueError(f"Invalid action: {action} for agent {aid}. Valid actions are: "
                              f"{list(ACTION_TO_DIRECTION)}")
-        actions[slot[aid]] = int(action)
-        order.append(slot[aid])
-    listed = set(order)
-    order += [i for i in range(n) if i not in listed]
-    return actions, np.asarray(order, np.uint8)
+        actions[i] = int(action)
+        order.append(i)
+    if len(order) != n:
+        listed = set(order)
+        order += [i for i in range(n) if i not in listed]
+    return actions, order
+
+
+def encode_actions(ids, action_dict):
+    """``action_dict`` -> (actions u8 [N] with 255 = absent, move order u8 [N]); raises the
+    reference's ``ValueError``s (collectivecrossing.py:685-711), agent check before action check."""
+    actions, order = _encode_lists(ids, {aid: i for i, aid in enumerate(ids)}, action_dict)
+    return np.asarray(actions, np.uint8), np.asarray(order, np.uint8)
 
 
 class CollectiveCrossingEnv(_Base):
@@ -120,7 +163,9 @@ class CollectiveCrossingEnv(_Base):
         nb = config.num_boarding_agents
         self._types = [AgentType.BOARDING if i < nb else AgentType.EXITING for i in range(len(self._ids))]
         self._type_names = [t.value for t in self._types]
+        self._slot = {aid: i for i, aid in enumerate(self._ids)}
         self._mirror = _Mirror(len(self._ids))
+        self._flags_version = -1     # version of the mirror the per-step flag lists were taken from
         self._agents: dict[str, Agent] = {aid: Agent(self._mirror, i, aid, self._types[i])
                                           for i, aid in enumerate(self._ids)}
         self._agents_truncated_or_terminated_this_step: set[str] = set()
@@ -163,8 +208,17 @@ class CollectiveCrossingEnv(_Base):
     @property
     def agents(self) -> list[str]:
         """Ids that are neither terminated nor truncated (collectivecrossing.py:743-768)."""
+        t, u = self._flag_lists()[1:]
+        return [aid for i, aid in enumerate(self._ids) if not t[i] and not u[i]]
+
+    def _flag_lists(self):
+        """(active, terminated, truncated) as python lists, cumulative, refreshed after external
+        writes to the mirror (``version``)."""
         m = self._mirror
-        return [aid for i, aid in enumerate(self._ids) if not m.terminated[i] and not m.truncated[i]]
+        if self._flags_version != m.version:
+            self._flags = (m.active.tolist(), m.terminated.tolist(), m.truncated.tolist())
+            self._flags_version = m.version
+        return self._flags
 
     @property
     def possible_agents(self) -> list[str]:
@@ -199,6 +253,7 @@ class CollectiveCrossingEnv(_Base):
             getattr(m, k)[:] = st[k][0]
         m.step_count = int(st["step_count"][0])
         m.dirty = False
+        m.touch()
 
     # ------------------------------------------------------------------ reset / step
     def reset(self, *, seed: int | None = None, options: dict | None = None):
@@ -207,12 +262,14 @@ class CollectiveCrossingEnv(_Base):
             self.np_random = make_generator(seed)        # gymnasium.Env.reset(seed=...)
         pos = sample_initial_positions(self._config, self.np_random)
         m = self._mirror
+        m._pending = None            # everything is overwritten below
         m.x[:], m.y[:] = pos[:, 0], pos[:, 1]
         m.active[:] = 1
         m.terminated[:] = 0
         m.truncated[:] = 0
         m.step_count = 0
         m.dirty = True
+        m.touch()
         self._upload()
         obs = self._batch.observe().cpu().numpy()[0]
         observations = {aid: np.array(obs[i]) for i, aid in enumerate(self._ids)}
@@ -233,11 +290,26 @@ class CollectiveCrossingEnv(_Base):
         o_ef = o_af + a16(n)
         total = o_ef + 16
         dev = self._batch.device
-        self._out_dev = torch.empty(total, dtype=torch.uint8, device=dev)
         self._out_host = torch.empty(total, dtype=torch.uint8).pin_memory()
-        self._in_dev = torch.empty(2 * n, dtype=torch.uint8, device=dev)
         self._in_host = torch.empty(2 * n, dtype=torch.uint8).pin_memory()
-        base = self._out_dev.data_ptr()
+        # zero-copy (default): pinned host memory is mapped into the GPU's address space at the same
+        # address, so the step kernel reads the actions from it and writes its ~1.5 KB of outputs
+        # straight into it over the host link -- a step is ONE launch + one stream sync, no memcpy
+        # calls.  CCX_ENV_STAGED=1 keeps device staging buffers and two async copies instead.
+        self._zero_copy = os.environ.get("CCX_ENV_STAGED", "0") != "1"
+        if self._zero_copy:
+            b, ptrs = self._batch, []
+            for t in (self._out_host, self._in_host):
+                d = C.c_void_p()
+                rc = b._lib.ccx_host_device_pointer(b._h, C.c_void_p(t.data_ptr()), C.byref(d))
+                ptrs.append(d.value if rc == 0 else None)
+            self._zero_copy = None not in ptrs
+        if self._zero_copy:
+            base, self._in_base = ptrs
+        else:
+            self._out_dev = torch.empty(total, dtype=torch.uint8, device=dev)
+            self._in_dev = torch.empty(2 * n, dtype=torch.uint8, device=dev)
+            base, self._in_base = self._out_dev.data_ptr(), self._in_dev.data_ptr()
         self._step_out = _abi.CcxStepOut(base + o_obs, base + o_rew, base + o_af, base + o_ef)
         h = self._out_host.numpy()
         self._h_obs = h[o_obs:o_obs + n * L * 4].view(np.float32).reshape(n, L)
@@ -245,41 +317,67 @@ class CollectiveCrossingEnv(_Base):
         self._h_af = h[o_af:o_af + n]
         self._h_ef = h[o_ef:o_ef + 1]
         self._h_in = self._in_host.numpy()
-        self._c_byref = C.byref
+        self._step_out_ref = C.byref(self._step_out)
 
     def step(self, action_dict):
         """One tick (collectivecrossing.py:161-261) on the GPU: one H2D copy (actions + move
         order), one ``ccx_step`` launch, one D2H copy (obs + rewards + flag bytes)."""
         import ctypes as C
 
-        actions, order = encode_actions(self._ids, action_dict)
+        ids = self._ids
+        n = len(ids)
+        actions, order = _encode_lists(ids, self._slot, action_dict)
         self._upload()
-        if not hasattr(self, "_out_dev"):
+        if not hasattr(self, "_in_base"):
             self._alloc_io()
-        n = len(self._ids)
-        self._h_in[:n] = actions
-        self._h_in[n:] = order
-        self._in_dev.copy_(self._in_host, non_blocking=True)
+        self._h_in[:] = actions + order
+        if not self._zero_copy:
+            self._in_dev.copy_(self._in_host, non_blocking=True)
         b = self._batch
-        base = self._in_dev.data_ptr()
-        from ._lib import check
-        check(b._lib.ccx_step(b._h, C.c_void_p(base), C.c_void_p(base + n), C.byref(self._step_out)))
-        self._out_host.copy_(self._out_dev, non_blocking=True)
+        base = self._in_base
+        rc = b._lib.ccx_step(b._h, base, base + n, self._step_out_ref)
+        if rc:
+            from ._lib import check
+            check(rc)
+        if not self._zero_copy:
+            self._out_host.copy_(self._out_dev, non_blocking=True)
         b.synchronize()
-        obs, reward, af, ef = self._h_obs, self._h_rew, self._h_af, int(self._h_ef[0])
-        # the new state is fully determined by the outputs: no state read-back
+        obs, ef = self._h_obs.copy(), int(self._h_ef[0])
+        flags, rew = self._h_af.tolist(), self._h_rew.tolist()
+        # the new state is fully determined by the outputs: no state read-back; the mirror arrays are
+        # brought up to date lazily (see _Mirror), only the flag lists are maintained per step
         m = self._mirror
-        before_done = m.terminated | m.truncated
-        m.x[:] = obs[:, 0].astype(np.int32)
-        m.y[:] = obs[:, 1].astype(np.int32)
-        m.active[:] = (af >> 6) & 1
-        m.terminated |= af & 1
-        m.truncated |= ((af >> 2) & 1) & ((af >> 1) & 1)
+        act_l, term_l, trunc_l = self._flag_lists()
+        types = self._type_names
+        observations, rewards, terminateds, truncateds, infos = {}, {}, {}, {}, {}
+        new_done = set()
+        for i, aid in enumerate(ids):
+            f = flags[i]
+            t = f & 1                                           # CCX_AF_TERMINATED
+            terminateds[aid] = t != 0
+            if f & 4:                                           # CCX_AF_LIVE
+                rewards[aid] = rew[i]
+                tr = f & 2                                      # CCX_AF_TRUNCATED
+                truncateds[aid] = tr != 0
+                if t | tr:
+                    if not (term_l[i] | trunc_l[i]):
+                        new_done.add(aid)
+                    if tr:
+                        trunc_l[i] = 1
+            if t:
+                term_l[i] = 1
+            act_l[i] = (f >> 6) & 1
+            if f & 8:                                           # CCX_AF_OBS
+                observations[aid] = obs[i]
+                infos[aid] = {"agent_type": types[i], "in_tram_area": (f & 0x10) != 0,
+                              "at_door": (f & 0x20) != 0, "active": (f & 0x40) != 0,
+                              "at_destination": (f & 0x80) != 0}
+        terminateds["__all__"] = (ef & _abi.EF_ALL_TERMINATED) != 0
+        truncateds["__all__"] = (ef & _abi.EF_ALL_TRUNCATED) != 0
+        m.defer(obs, act_l, term_l, trunc_l)
         m.step_count += 1
-        out = decode_step(self._ids, obs, reward, af, ef, self._type_names)
-        now_done = m.terminated | m.truncated
-        self._agents_truncated_or_terminated_this_step = {
-            aid for i, aid in enumerate(self._ids) if now_done[i] and not before_done[i]}
+        self._agents_truncated_or_terminated_this_step = new_done
+        out = (observations, rewards, terminateds, truncateds, infos)
         out = self._apply_custom_strategies(out)
         return out
 

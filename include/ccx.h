@@ -258,6 +258,12 @@ int ccx_get_launch_shape(ccx_handle* h, int32_t* lanes_per_wave, int32_t* waves_
                          int32_t* group_lanes, int32_t* num_blocks);
 
 /* rebind the handle to another HIP stream of its device (synchronises the old one first) */
+/* Zero-copy I/O for single-env stepping (the dict API of collectivecrossing.py:161-261 needs every
+ * output on the host after each step): the device address of page-locked host memory (hipHostMalloc /
+ * hipHostRegister, e.g. a torch pinned tensor).  Pass it to ccx_step as actions / outputs and the
+ * kernel reads and writes the host buffer over the host link -- one launch + one sync per step,
+ * no memcpy.  Fails with CCX_EINVAL for pageable or unregistered memory. */
+int ccx_host_device_pointer(ccx_handle* h, void* pinned_host, void** device_ptr);
 int ccx_set_stream(ccx_handle* h, void* stream);
 int ccx_synchronize(ccx_handle* h);
 

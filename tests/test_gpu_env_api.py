@@ -330,3 +330,39 @@ def test_vector_adapter_views_equal_independent_dict_envs(Env):
     vec.close()
     for env in singles:
         env.close()
+
+
+def test_zero_copy_and_staged_step_io_agree(Env, monkeypatch):
+    """The default step writes its outputs straight into pinned host memory (ccx_host_device_pointer);
+    CCX_ENV_STAGED=1 uses device buffers + two copies.  Same dicts, same lazily synced mirror."""
+    rng = np.random.default_rng(3)
+    cfg = _cfg()
+    runs = []
+    for staged in ("0", "1"):
+        monkeypatch.setenv("CCX_ENV_STAGED", staged)
+        env = Env(config=cfg)
+        env.reset(seed=11)
+        rng = np.random.default_rng(3)
+        trace = []
+        for _ in range(60):
+            acts = {a: int(rng.integers(0, 5)) for a in env.agents}
+            obs, rew, term, trunc, infos = env.step(acts)
+            trace.append(({k: v.tolist() for k, v in obs.items()}, rew, term, trunc, infos,
+                          {a: (ag.x, ag.y, ag.active, ag.terminated, ag.truncated)
+                           for a, ag in env._agents.items()}, list(env.agents)))
+        assert env._zero_copy == (staged == "0")
+        runs.append(trace)
+        env.close()
+    assert runs[0] == runs[1]
+
+
+def test_host_device_pointer_rejects_pageable_memory(Env):
+    import ctypes as C
+
+    env = Env(config=_cfg())
+    b = env._batch
+    pageable = np.zeros(64, np.uint8)
+    out = C.c_void_p()
+    rc = b._lib.ccx_host_device_pointer(b._h, C.c_void_p(pageable.ctypes.data), C.byref(out))
+    assert rc != 0 and b"page-locked" in b._lib.ccx_last_error()
+    env.close()
