@@ -7,7 +7,7 @@ for rep in 1 2; do
   for L in $1; do
     for W in $2; do
       X="--chunk 500 --steps 2000 --warmup 500"; [ $W != c2 ] && X="--chunk 50 --steps 300 --warmup 50 --pool 512"
-      CCX_DIAG_LIB=collectivecrossing_amd/csrc/_diag/libccx_$L.so timeout -k 10 200 python bench.py --no-cpu-baseline --workload $W $X > gpurun_out/ab/${L}_${W}_$rep.json 2> gpurun_out/ab/${L}_${W}_$rep.err || { tail -3 gpurun_out/ab/${L}_${W}_$rep.err; exit 1; }
+      CCX_DIAG_LIB=collectivecrossing_amd/csrc/_diag/libccx_$L.so timeout -k 10 90 python bench.py --no-cpu-baseline --workload $W $X > gpurun_out/ab/${L}_${W}_$rep.json 2> gpurun_out/ab/${L}_${W}_$rep.err || { tail -3 gpurun_out/ab/${L}_${W}_$rep.err; exit 1; }
     done
   done
 done
@@ -18,4 +18,12 @@ for f in sorted(glob.glob("gpurun_out/ab/*.json")):
     L,W,_=f.split("/")[-1][:-5].rsplit("_",2)
     d=json.loads(open(f).read().strip().splitlines()[-1]); r[(W,L)].append(d["roofline"]["frac"])
 for k in sorted(r): print(k, ["%.4f"%v for v in r[k]])
+PY
+python - <<PY
+import json,glob,collections
+c=collections.defaultdict(set)
+for f in sorted(glob.glob("gpurun_out/ab/*.json")):
+    L,W,_=f.split("/")[-1][:-5].rsplit("_",2)
+    d=json.loads(open(f).read().strip().splitlines()[-1]); c[W].add(json.dumps(d["counters"],sort_keys=True))
+for W in c: print("counters identical across variants for", W, ":", len(c[W])==1)
 PY
