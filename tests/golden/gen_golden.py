@@ -201,6 +201,52 @@ def cfg_small(**over):
     return c
 
 
+def cfg_fuzz(index: int) -> dict:
+    """Random but reference-VALID config number ``index`` (the reference's own validators decide):
+    geometry, door width (incl. sealed), agent counts, destination rows, every reward / termination
+    strategy with random parameters, short max_steps so truncation happens inside the recording."""
+    rng = np.random.default_rng(9000 + index)
+    for _ in range(10000):
+        W, H = int(rng.integers(4, 27)), int(rng.integers(4, 19))
+        div = int(rng.integers(1, H))
+        Lt = int(rng.integers(2, W + 1))
+        dl = int(rng.integers(0, Lt))
+        dr = int(rng.integers(dl + 1, Lt + 1))
+        tl, tr = W // 2 - Lt // 2, W // 2 + Lt // 2
+        cap_b = W * div - (dr - dl + 1)                       # reset() also rejects cells under the door
+        cap_e = max(0, tr - tl - 1) * max(0, H - div - 1)
+        nb = int(rng.integers(0, max(1, min(14, cap_b // 3) + 1)))
+        ne = int(rng.integers(0, max(1, min(12, cap_e // 3) + 1)))
+        if nb + ne < 1:
+            continue
+        reward = [dict(reward_function="default",
+                       boarding_destination_reward=float(np.round(rng.uniform(-20, 20), 3)),
+                       tram_door_reward=float(np.round(rng.uniform(-20, 20), 3)),
+                       tram_area_reward=float(np.round(rng.uniform(-20, 20), 3)),
+                       distance_penalty_factor=float(rng.choice([0.0, 0.1, 0.37, 1.0, 2.5, 7.3]))),
+                  dict(reward_function="simple_distance",
+                       distance_penalty_factor=float(rng.choice([0.0, 0.1, 0.7, 3.3]))),
+                  dict(reward_function="binary", goal_reward=float(np.round(rng.uniform(0, 9), 2)),
+                       no_goal_reward=float(np.round(rng.uniform(-3, 3), 2))),
+                  dict(reward_function="constant_negative",
+                       step_penalty=float(np.round(rng.uniform(-5, 0), 3)))][int(rng.integers(0, 4))]
+        cfg = dict(width=W, height=H, division_y=div, tram_door_left=dl, tram_door_right=dr, tram_length=Lt,
+                   num_boarding_agents=nb, num_exiting_agents=ne,
+                   exiting_destination_area_y=int(rng.integers(0, div)),
+                   boarding_destination_area_y=int(rng.integers(div, H + 1)),
+                   reward_config=reward,
+                   terminated_config=dict(terminated_function=str(rng.choice(
+                       ["individual_at_destination", "all_at_destination"]))),
+                   truncated_config=dict(truncated_function=str(rng.choice(["max_steps", "custom"])),
+                                         max_steps=int(rng.integers(5, 40))))
+        try:
+            build_ref_config(cfg)
+        except Exception:   # noqa: BLE001 -- the reference's pydantic validators reject it: draw again
+            continue
+        return cfg
+    raise RuntimeError("no valid fuzz config found")
+
+
 # ------------------------------------------------------------------------------------ drivers
 def run_random(name, cfg, seeds, K, shuffle=False, p_absent=0.0, act_done=True):
     """reset(seed=s) then K steps of uniform random actions (keeps stepping after __all__)."""
@@ -449,6 +495,16 @@ def main() -> int:
         terminated_config=dict(terminated_function="all_at_destination")), seeds=range(510, 518), K=56,
         policy="waiting")
     run_greedy("g9_c5_waiting_policy_25_25", cfg_c5(25, 25, max_steps=70), seeds=[520], K=74, policy="waiting")
+    # G10: random reference-valid configs (geometry x strategies), shuffled dict order, omitted agents
+    for i in range(20):
+        run_random(f"g10_fuzz_{i:02d}", cfg_fuzz(i), seeds=range(700 + 10 * i, 703 + 10 * i), K=44,
+                   shuffle=bool(i & 1), p_absent=0.1 if i % 3 == 0 else 0.0)
+    # ... and the same family driven by the reference's greedy / waiting policies (arrivals, door
+    # traffic, terminations), max_steps long enough to finish
+    for i in range(20, 32):
+        cfg = dict(cfg_fuzz(i), truncated_config=dict(truncated_function="max_steps", max_steps=70))
+        pol = "waiting" if i % 3 == 2 else "greedy"
+        run_greedy(f"g10_fuzz_{pol}_{i:02d}", cfg, seeds=[900 + 2 * i, 901 + 2 * i], K=74, policy=pol)
     return 0
 
 

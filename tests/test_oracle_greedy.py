@@ -38,4 +38,6 @@ def test_waiting_policy_actions_match_the_reference_policy(oracle, name):
         np.testing.assert_array_equal(acts, g["actions"][s], err_msg=f"{name} step {s}")
         waited += int(((acts == 4) & (b.greedy_actions() != 4)).sum())
         b.step(g["actions"][s], g["order"][s], want_obs=False)
-    assert len(WAITING) >= 3 and waited > 0, "the fixture must contain steps where waiting != greedy"
+    assert len(WAITING) >= 3
+    if name.startswith("g9_"):   # (a fuzz config may have no exiting agents to wait for)
+        assert waited > 0, "the fixture must contain steps where waiting != greedy"
