@@ -323,7 +323,7 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     alloc((void**)&h->st.truncated, en);
     alloc((void**)&h->st.step_count, (size_t)h->E * 4);
     alloc((void**)&h->st.episode, (size_t)h->E * 4);
-    alloc((void**)&h->counters, 16 * sizeof(unsigned long long));
+    alloc((void**)&h->counters, ccx::counter_words(h->E) * sizeof(unsigned long long));
     alloc((void**)&h->placement_scratch, en * 2);
     const std::vector<unsigned long long> cell_tab = build_cell_table(*params);
     alloc((void**)&h->cell_info, cell_tab.size() * sizeof(unsigned long long));
@@ -339,7 +339,8 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     if (e == hipSuccess) e = hipMemsetAsync(h->st.truncated, 0, en, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->st.step_count, 0, (size_t)h->E * 4, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->st.episode, 0, (size_t)h->E * 4, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->counters, 0, 16 * sizeof(unsigned long long), h->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(h->counters, 0, ccx::counter_words(h->E) * sizeof(unsigned long long), h->stream);
     if (e != hipSuccess) {
         int code = (e == hipErrorOutOfMemory) ? CCX_ENOMEM : CCX_EHIP;
         fail(code, "ccx_create: %s", hipGetErrorString(e));
@@ -569,7 +570,7 @@ int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t
 int ccx_zero_counters(ccx_handle* h) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");
     CCX_HIP(hipSetDevice(h->device));
-    CCX_HIP(hipMemsetAsync(h->counters, 0, 16 * sizeof(unsigned long long), h->stream));
+    CCX_HIP(hipMemsetAsync(h->counters, 0, ccx::counter_words(h->E) * sizeof(unsigned long long), h->stream));
     return CCX_OK;
 }
 
@@ -577,6 +578,7 @@ int ccx_read_counters(ccx_handle* h, ccx_counters* out_host) {
     if (!h || !out_host) return fail(CCX_EINVAL, "NULL argument");
     static_assert(sizeof(ccx_counters) == 6 * sizeof(unsigned long long), "counter layout");
     CCX_HIP(hipSetDevice(h->device));
+    CCX_HIP(ccx::launch_reduce_counters(h->stream, h->counters, h->E));
     CCX_HIP(hipStreamSynchronize(h->stream));
     CCX_HIP(hipMemcpy(out_host, h->counters, sizeof(ccx_counters), hipMemcpyDeviceToHost));
     return CCX_OK;
@@ -584,6 +586,8 @@ int ccx_read_counters(ccx_handle* h, ccx_counters* out_host) {
 
 int ccx_counters_device_ptr(ccx_handle* h, uint64_t** out) {
     if (!h || !out) return fail(CCX_EINVAL, "NULL argument");
+    CCX_HIP(hipSetDevice(h->device));
+    CCX_HIP(ccx::launch_reduce_counters(h->stream, h->counters, h->E));
     *out = reinterpret_cast<uint64_t*>(h->counters);
     return CCX_OK;
 }

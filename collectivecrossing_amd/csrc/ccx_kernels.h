@@ -52,6 +52,12 @@ struct KOut {
     uint8_t* env_flags;
 };
 
+// Device counters: [0..5] totals (ccx_counters), [7] failed placements, [8..15] diagnostic builds, then
+// one slot of kCounterSlot words per env tile that the rollout kernel adds to (a tile index never
+// exceeds the env count); launch_reduce_counters sums the slots into the totals.
+constexpr unsigned kCounterTotals = 16, kCounterSlot = 8;
+inline size_t counter_words(int num_envs) { return kCounterTotals + (size_t)kCounterSlot * (size_t)num_envs; }
+
 struct LaunchShape {
     int glog;             // log2 of the per-env lane group
     int envs_per_wave;    // EW
@@ -69,6 +75,7 @@ hipError_t launch_rollout(const LaunchShape& ls, hipStream_t stream, const KPara
                           const uint8_t* actions, const uint8_t* order, int K,
                           int auto_reset, const uint8_t* pool, const KOut& out,
                           unsigned long long* counters, int policy = 0, uint8_t* actions_out = nullptr);
+hipError_t launch_reduce_counters(hipStream_t stream, unsigned long long* counters, int slots);
 hipError_t launch_observe(const LaunchShape& ls, hipStream_t stream, const KParams& p,
                           const KState& st, float* obs);
 hipError_t launch_reset_from_pool(hipStream_t stream, const KParams& p, const KState& st,

@@ -821,15 +821,45 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
         const uint32_t nenv = wave_sum_u32((valid_env && i == 0) ? 1u : 0u);
         const uint32_t moves = wave_sum_u32(c_moves), arrivals = wave_sum_u32(c_arrivals);
         const uint32_t lives = wave_sum_u32(c_live), eps = wave_sum_u32(c_episodes);
+        // One partial slot per tile: every wave adding to the SAME six words costs ~35 us per
+        // launch when all tiles finish together (3072 same-address device-scope atomics serialise
+        // at the memory side); distinct lines are free.  reduce_counters_kernel sums the slots.
         if (lane == 0 && nenv) {
-            atomicAdd(&ctr[0], (unsigned long long)nenv * (unsigned long long)K);
-            atomicAdd(&ctr[1], (unsigned long long)nenv * (unsigned long long)K * N);
-            atomicAdd(&ctr[2], (unsigned long long)lives);
-            atomicAdd(&ctr[3], (unsigned long long)eps);
-            atomicAdd(&ctr[4], (unsigned long long)moves);
-            atomicAdd(&ctr[5], (unsigned long long)arrivals);
+            unsigned long long* slot = ctr + kCounterTotals + (size_t)tile * kCounterSlot;
+            atomicAdd(&slot[0], (unsigned long long)nenv * (unsigned long long)K);
+            atomicAdd(&slot[1], (unsigned long long)nenv * (unsigned long long)K * N);
+            atomicAdd(&slot[2], (unsigned long long)lives);
+            atomicAdd(&slot[3], (unsigned long long)eps);
+            atomicAdd(&slot[4], (unsigned long long)moves);
+            atomicAdd(&slot[5], (unsigned long long)arrivals);
         }
     }
+}
+
+// totals[q] = sum over the per-tile partial slots (q = 0..5); one workgroup
+__global__ void __launch_bounds__(256) reduce_counters_kernel(unsigned long long* counters, int slots) {
+    __shared__ unsigned long long part[4][6];
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int t = threadIdx.x; t < slots; t += 256) {
+        const unsigned long long* slot = counters + kCounterTotals + (size_t)t * kCounterSlot;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc[q] += slot[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_xor(acc[q], off, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][q] = acc[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6)
+        counters[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] +
+                                part[3][threadIdx.x];
+}
+
+hipError_t launch_reduce_counters(hipStream_t stream, unsigned long long* counters, int slots) {
+    hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, stream, counters, slots);
+    return hipGetLastError();
 }
 
 // DefaultObservation of the current state (what reset() returns, collectivecrossing.py:153-159)

@@ -235,7 +235,9 @@ int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t
 
 int ccx_zero_counters(ccx_handle* h);
 int ccx_read_counters(ccx_handle* h, ccx_counters* out_host);   /* synchronous */
-/* device pointer to the 6 u64 counters (for an RCCL all-reduce by the caller) */
+/* device pointer to the 6 u64 counters (for an RCCL all-reduce by the caller).  The rollout kernel
+ * accumulates per-tile partial counters; this call enqueues their reduction on the handle's stream, so
+ * the totals cover every launch enqueued BEFORE it (call it again after later launches). */
 int ccx_counters_device_ptr(ccx_handle* h, uint64_t** out);
 
 /* timing of the most recent ccx_step / ccx_rollout launch, measured with HIP events recorded on

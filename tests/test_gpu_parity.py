@@ -408,6 +408,18 @@ def test_autoreset_rollout_equals_oracle(oracle, ccx, cfg_name, E, K):
     assert c["episodes"] > 0
 
 
+FUZZ = [n for n in STEP_NPZ if n.startswith("g10_fuzz_")]
+
+
+@pytest.mark.parametrize("name", FUZZ[::2])
+def test_fuzz_configs_at_batch_sizes_the_goldens_do_not_reach(oracle, ccx, name):
+    """Random reference-valid configs (the g10 family) at a few hundred envs with shuffled move
+    order, omitted agents and auto-reset: kernel vs oracle, bit-exact."""
+    k = FUZZ.index(name)
+    _random_case(oracle, ccx, name, E=130 + 37 * k, K=70, seed=40 + k, shuffle=bool(k & 2), auto_reset=bool(k & 4),
+                 p_absent=0.08 if k % 3 == 0 else 0.0)
+
+
 def test_full_size_c2_properties(ccx):
     """BASELINE config 2 at full size (4096 x 8): size-independent properties of a long
     auto-reset rollout -- no two active agents ever share a cell, nobody stands in a wall,
@@ -565,6 +577,46 @@ def test_handle_can_be_moved_to_another_stream(ccx):
     side.synchronize()
     _check_rollout_vs_golden(g, res, env.get_state())
     env.close()
+
+
+def test_policy_in_the_loop_stepping_captures_into_a_hip_graph(ccx):
+    """A step-wise loop (policy kernel -> ``ccx_step``) is launch-bound; both calls only enqueue
+    kernels on the handle's stream, so the pair captures into a HIP graph (torch.cuda.graph) that is
+    replayed per step.  Result = the fused in-kernel policy rollout, bit for bit."""
+    import torch
+
+    g = Golden("g4_c1_individual_greedy")
+    K = 40
+    ref = ccx(g.config, g.E)
+    ref.set_state(**g.init_state())
+    want, want_actions = ref.rollout_greedy(K)
+    env = ccx(g.config, g.E)
+    env.set_state(**g.init_state())
+    side = torch.cuda.Stream(device=env.device)
+    env.use_stream(side)                       # bind BEFORE the capture starts (set_stream syncs)
+    acts = torch.empty((g.E, g.N), dtype=torch.uint8, device=env.device)
+    with torch.cuda.stream(side):
+        env.greedy_actions(out=acts)           # warm-up outside the capture (allocates the step buffers)
+        env.step(acts)
+        side.synchronize()
+        env.set_state(**g.init_state())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            env.greedy_actions(out=acts)
+            out = env.step(acts)
+        for s in range(K):
+            graph.replay()
+            side.synchronize()
+            np.testing.assert_array_equal(_np(acts), _np(want_actions[s]), err_msg=f"actions step {s}")
+            np.testing.assert_array_equal(_np(out.obs).view(np.uint32), _np(want.obs[s]).view(np.uint32))
+            np.testing.assert_array_equal(_np(out.reward).view(np.uint64), _np(want.reward[s]).view(np.uint64))
+            np.testing.assert_array_equal(_np(out.agent_flags), _np(want.agent_flags[s]))
+            np.testing.assert_array_equal(_np(out.env_flags), _np(want.env_flags[s]))
+    st, st_ref = env.get_state(), ref.get_state()
+    for k in ("x", "y", "active", "terminated", "truncated", "step_count"):
+        np.testing.assert_array_equal(st[k], st_ref[k], err_msg=k)
+    env.close()
+    ref.close()
 
 
 def test_errors_are_loud(ccx):
