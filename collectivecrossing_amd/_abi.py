@@ -108,6 +108,7 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_zero_counters": (C.c_int, [_H]),
     "ccx_read_counters": (C.c_int, [_H, C.POINTER(CcxCounters)]),
     "ccx_counters_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    "ccx_set_timing": (C.c_int, [_H, C.c_int32]),
     "ccx_last_launch_ms": (C.c_int, [_H, C.POINTER(C.c_float)]),
     "ccx_set_launch_shape": (C.c_int, [_H, C.c_int32, C.c_int32]),
     "ccx_set_writers": (C.c_int, [_H, C.c_int32]),

@@ -278,6 +278,10 @@ class BatchedCollectiveCrossing:
         check(self._lib.ccx_counters_device_ptr(self._h, C.byref(p)))
         return _device_view_i64(p.value, len(_abi.COUNTER_FIELDS), self.device)
 
+    def set_timing(self, enabled: bool = True) -> None:
+        """Record HIP events around every launch so that ``last_launch_ms`` works (off by default)."""
+        check(self._lib.ccx_set_timing(self._h, int(bool(enabled))))
+
     def last_launch_ms(self) -> float:
         ms = C.c_float()
         check(self._lib.ccx_last_launch_ms(self._h, C.byref(ms)))

@@ -57,6 +57,7 @@ struct ccx_handle {
     int64_t pool_size = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
+    bool timing = false;                                       // record HIP events around launches
     int lanes_per_wave = 0, waves_per_block = 0, writers = 0;  // user overrides (0 = default)
     int store_throttle = 0;                                    // 0 = default, -1 = off, >0 = stores in flight
     ccx::LaunchShape shape{};
@@ -236,12 +237,14 @@ int validate_params(const ccx_params* p) {
 }
 
 int begin_timed(ccx_handle* h) {
-    CCX_HIP(hipEventRecord(h->ev_start, h->stream));
+    if (h->timing) CCX_HIP(hipEventRecord(h->ev_start, h->stream));
     return CCX_OK;
 }
 int end_timed(ccx_handle* h) {
-    CCX_HIP(hipEventRecord(h->ev_stop, h->stream));
-    h->timed = true;
+    if (h->timing) {
+        CCX_HIP(hipEventRecord(h->ev_stop, h->stream));
+        h->timed = true;
+    }
     return CCX_OK;
 }
 
@@ -592,9 +595,16 @@ int ccx_counters_device_ptr(ccx_handle* h, uint64_t** out) {
     return CCX_OK;
 }
 
+int ccx_set_timing(ccx_handle* h, int32_t enabled) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    h->timing = enabled != 0;
+    if (!h->timing) h->timed = false;
+    return CCX_OK;
+}
+
 int ccx_last_launch_ms(ccx_handle* h, float* ms) {
     if (!h || !ms) return fail(CCX_EINVAL, "NULL argument");
-    if (!h->timed) return fail(CCX_EINVAL, "no timed launch yet");
+    if (!h->timed) return fail(CCX_EINVAL, "no timed launch yet (enable with ccx_set_timing(h, 1))");
     CCX_HIP(hipSetDevice(h->device));
     CCX_HIP(hipEventSynchronize(h->ev_stop));
     CCX_HIP(hipEventElapsedTime(ms, h->ev_start, h->ev_stop));

@@ -240,8 +240,11 @@ int ccx_read_counters(ccx_handle* h, ccx_counters* out_host);   /* synchronous *
  * the totals cover every launch enqueued BEFORE it (call it again after later launches). */
 int ccx_counters_device_ptr(ccx_handle* h, uint64_t** out);
 
-/* timing of the most recent ccx_step / ccx_rollout launch, measured with HIP events recorded on
- * the handle's stream around the kernel; synchronises on the stop event. */
+/* Launch timing, off by default (two event records per launch cost a step-wise loop several
+ * microseconds per step): when enabled, HIP events are recorded on the handle's stream around every
+ * ccx_step / ccx_rollout kernel and ccx_last_launch_ms returns the duration of the most recent one
+ * (it synchronises on the stop event). */
+int ccx_set_timing(ccx_handle* h, int32_t enabled);
 int ccx_last_launch_ms(ccx_handle* h, float* ms);
 
 /* launch-shape tuning (0 = library default): lanes of each 64-wide wavefront that carry agents

@@ -23,6 +23,7 @@ writers = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 E, K, N = 4096, 256, 8
 cfg = c2_config()
 env = BatchedCollectiveCrossing(cfg, E)
+env.set_timing(True)
 if lanes:
     env.set_launch_shape(lanes, 0)
 if writers:

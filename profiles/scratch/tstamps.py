@@ -16,6 +16,7 @@ from collectivecrossing_amd.batched import BatchedCollectiveCrossing, _device_vi
 
 E, N = 4096, 8
 env = BatchedCollectiveCrossing(c2_config(), E)
+env.set_timing(True)
 env.make_reset_pool(0, 1024, on_device=True)
 env.reset_from_pool()
 acts = torch.randint(0, 5, (64, E, N), dtype=torch.uint8, device=env.device)
