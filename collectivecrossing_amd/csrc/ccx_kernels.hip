@@ -350,13 +350,25 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             char* act_s = small_out ? reinterpret_cast<char*>(actions_out) : nullptr;   // policy rollouts
             char* obs_s = reinterpret_cast<char*>(out.obs) + (size_t)env0 * N * L * 4;
             const size_t obs_stride = EN * (size_t)L * 4;
+            // Store iterations are laid out on 128-byte lines of GLOBAL memory, not from the start of
+            // the tile's region: a region that starts mid-line (most agent counts; N = 50: 41200 B
+            // per env) would otherwise make every 1-KiB wave store straddle two partially written
+            // lines (measured 4.1 vs 6.1 TB/s).  `lead` = vector units between the line boundary
+            // below the region and its start; constant over the steps when the slab stride is a
+            // multiple of 128 bytes (else 0: the old, region-relative layout).
+            const uint32_t vbytes = PAIR ? 16u : 8u;
+            const uint32_t lead = __builtin_amdgcn_readfirstlane(
+                ((obs_stride & 127u) == 0 && want_obs)
+                    ? (uint32_t)(reinterpret_cast<uintptr_t>(obs_s) & 127u) / vbytes : 0u);
+            obs_s -= lead * vbytes;                       // line-aligned base; unit q lives at (q + lead)
+            const int n4l = n4 + (int)lead;               // one past the last slot of the shifted layout
             // LDS source addresses of this lane's first kFastObsIters observation stores
             uint32_t oa0[kFastObsIters], oa1[kFastObsIters];
 #pragma unroll
             for (int j = 0; j < kFastObsIters; ++j) {
-                const int q = lane + 64 * (w + nw * j);
+                const uint32_t q = (uint32_t)(lane + 64 * (w + nw * j)) - lead;   // wraps below the region
                 oa0[j] = oa1[j] = kCstOff + 16u;
-                if (want_obs && q < n4) {
+                if (want_obs && q < (uint32_t)n4) {
                     if constexpr (PAIR) {
                         const uint32_t t = reinterpret_cast<const uint32_t*>(table)[q];
                         oa0[j] = t & 0xFFFFu;
@@ -366,7 +378,6 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                     }
                 }
             }
-            const uint32_t vbytes = PAIR ? 16u : 8u;
             const uint32_t q0_off = (uint32_t)(lane + 64 * w) * vbytes;   // byte offset of iteration 0
             const uint32_t it_stride = 64u * (uint32_t)nw * vbytes;       // between my iterations
             const char* sbase = reinterpret_cast<const char*>(wl);
@@ -410,7 +421,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                     // wave pays one LDS latency per batch, then the stores
 #pragma unroll
                     for (int j0 = 0; j0 < kFastObsIters; j0 += kObsBatch) {
-                        if (64 * (w + nw * j0) < n4) {
+                        if (64 * (w + nw * j0) < n4l) {
                             float2 va[kObsBatch], vb[kObsBatch];
 #pragma unroll
                             for (int j = 0; j < kObsBatch; ++j) {
@@ -420,8 +431,8 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                             }
 #pragma unroll
                             for (int j = 0; j < kObsBatch; ++j) {
-                                const int q = lane + 64 * (w + nw * (j0 + j));
-                                if (q < n4) {
+                                const uint32_t q = (uint32_t)(lane + 64 * (w + nw * (j0 + j))) - lead;
+                                if (q < (uint32_t)n4) {
                                     char* dst = obs_s + (q0_off + (uint32_t)(j0 + j) * it_stride);
                                     if constexpr (PAIR) {
                                         v4f v = {va[j].x, va[j].y, vb[j].x, vb[j].y};
@@ -434,15 +445,17 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                         }
                     }
                     // beyond the register-cached iterations: table-driven
-                    for (int q = lane + 64 * (w + nw * kFastObsIters); q < n4; q += 64 * nw) {
+                    for (int ql = lane + 64 * (w + nw * kFastObsIters); ql < n4l; ql += 64 * nw) {
+                        const uint32_t q = (uint32_t)ql - lead;
+                        if (q >= (uint32_t)n4) continue;
                         if constexpr (PAIR) {
                             const uint32_t t = reinterpret_cast<const uint32_t*>(table)[q];
                             float2 a2 = *reinterpret_cast<const float2*>(sbase + (t & 0xFFFFu));
                             float2 b2 = *reinterpret_cast<const float2*>(sbase + (t >> 16));
                             v4f v = {a2.x, a2.y, b2.x, b2.y};
-                            store_obs(v, reinterpret_cast<v4f*>(obs_s + (size_t)q * 16));
+                            store_obs(v, reinterpret_cast<v4f*>(obs_s + (size_t)ql * 16));
                         } else {
-                            *reinterpret_cast<float2*>(obs_s + (size_t)q * 8) =
+                            *reinterpret_cast<float2*>(obs_s + (size_t)ql * 8) =
                                 *reinterpret_cast<const float2*>(sbase + table[q]);
                         }
                     }
