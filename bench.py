@@ -4,10 +4,12 @@
 Workload (BASELINE.json configs[1], SURVEY 8d "C2"): per GPU 4096 envs x 8 agents (5 boarding +
 3 exiting) on the 12x8 grid, DefaultReward + DefaultObservation, IndividualAtDestination,
 MaxSteps=100, uniform random actions read from a device tensor, auto-reset from a pool of
-reference-exact seeded placements.  A bench "step" = ONE env-step of every env of the batch, i.e.
-one pass of the hot path over the batch; steps are executed `--chunk` at a time by the fused
-``ccx_rollout`` kernel, which writes the full per-step outputs (observations f32 [E,N,L], rewards
-f64, flag bytes) of every step to a trajectory buffer in HBM.
+reference-exact seeded placements.  A bench "step" = ONE pass of the hot path over one batch of
+synthetic input: one fused ``ccx_rollout`` launch that advances every env of the batch by `--chunk`
+(default 500) env-steps from an action tensor [chunk, E, N] resident in HBM and writes the full
+per-step outputs (observations f32 [E,N,L], rewards f64, flag bytes) of every env-step to a trajectory
+buffer in HBM.  `--steps K` / `--warmup W` count such launches (K = 40: 20000 env-steps of 4096 envs);
+the metric stays env-steps/s = K * chunk * envs / elapsed.
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
@@ -155,11 +157,11 @@ def cpu_baseline(config, n_agents: int, seconds_target: float = 12.0) -> dict:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=40, help="timed rollout launches (bench steps)")
+    ap.add_argument("--warmup", type=int, default=4, help="untimed rollout launches")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the workload's own size")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5_50", "c5_64"])
-    ap.add_argument("--chunk", type=int, default=500, help="env-steps fused per kernel launch")
+    ap.add_argument("--chunk", type=int, default=500, help="env-steps fused per rollout launch (= per bench step)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave carrying agents (0=auto)")
     ap.add_argument("--wpb", type=int, default=0, help="env tiles per workgroup (0=auto)")
     ap.add_argument("--writers", type=int, default=0, help="writer waves per env tile (0=auto)")
@@ -206,33 +208,30 @@ def main() -> int:
     env.make_reset_pool(0, args.pool, on_device=not os.environ.get("CCX_DIAG_LIB"))  # seeds 0..pool-1
     env.reset_from_pool()
 
-    chunk = max(1, min(args.chunk, args.steps))
+    chunk = max(1, args.chunk)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    # the action stream is `n_act` steps long (a multiple of the launch size) and wraps around
-    n_act = max(chunk, min(max(args.steps, args.warmup, 1), 4000) // chunk * chunk)
-    actions = torch.randint(0, 5, (n_act, E, N), dtype=torch.uint8, device=dev, generator=gen)
+    # the action stream holds `n_buf` launches worth of steps and wraps around
+    n_buf = max(1, min(max(args.steps, args.warmup, 1), 8))
+    actions = torch.randint(0, 5, (n_buf * chunk, E, N), dtype=torch.uint8, device=dev, generator=gen)
     traj = env.alloc_rollout(chunk, want_obs=not args.no_obs)
+    view = traj if not args.only_obs else type(traj)(traj.obs, None, None, None)
+    launched = 0
 
-    def run(nsteps, events=None):
-        done = 0
-        while done < nsteps:
-            k = min(chunk, nsteps - done)
-            view = type(traj)(None if traj.obs is None else traj.obs[:k], traj.reward[:k],
-                              traj.agent_flags[:k], traj.env_flags[:k])
-            if args.only_obs:
-                view = type(traj)(view.obs, None, None, None)
+    def run(nlaunches, events=None):
+        nonlocal launched
+        for _ in range(nlaunches):
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if args.policy == "greedy":
-                env.rollout_greedy(k, auto_reset=True, out=view, want_actions=False)
+                env.rollout_greedy(chunk, auto_reset=True, out=view, want_actions=False)
             else:
-                a0 = done % n_act
-                env.rollout(actions[a0:a0 + k], auto_reset=True, out=view)
+                a0 = (launched % n_buf) * chunk
+                env.rollout(actions[a0:a0 + chunk], auto_reset=True, out=view)
+            launched += 1
             if events is not None:
                 e1.record()
-                events.append((e0, e1, k))
-            done += k
+                events.append((e0, e1))
 
     run(args.warmup)
     env.zero_counters()
@@ -249,8 +248,8 @@ def main() -> int:
     counters = sharding.allreduce_counters(env.counters())   # the one RCCL reduction (48 B)
 
     # kernel time from HIP events recorded on the launch stream, per launch
-    full = [(a.elapsed_time(b), k) for a, b, k in events if k == chunk]
-    kern_ms = float(np.mean([ms for ms, _ in full])) if full else float("nan")
+    full = [a.elapsed_time(b) for a, b in events]
+    kern_ms = float(np.mean(full)) if full else float("nan")
     bytes_unit = rollout_bytes_per_agent_step(N) - (4 * L if args.no_obs else 0)
     launch_bytes = bytes_unit * chunk * E * N
     achieved = launch_bytes / (kern_ms * 1e-3) / 1e9 if full else float("nan")
@@ -267,9 +266,9 @@ def main() -> int:
 
     probe = write_bandwidth_probe(dev, traj.obs if traj.obs is not None else traj.reward) if rank == 0 else None
     if rank == 0:
-        assert os.environ.get("CCX_DIAG_LIB") or counters["env_steps"] == args.steps * total, counters
+        assert os.environ.get("CCX_DIAG_LIB") or counters["env_steps"] == args.steps * chunk * total, counters
         props = torch.cuda.get_device_properties(dev)
-        env_sps = args.steps * total / elapsed
+        env_sps = args.steps * chunk * total / elapsed
         line = {
             "metric": f"env-steps/sec, random-action rollout, {E} envs x {N} agents per GPU",
             "value": env_sps, "unit": "env-steps/s", "agent_steps_per_sec": env_sps * N,
@@ -286,7 +285,10 @@ def main() -> int:
                        else f"{args.workload} (diagnostic, not the bench line)",
                        "policy": args.policy,
                        "envs_per_gpu": E, "global_envs": total, "agents": N, "obs_len": L,
-                       "steps_per_launch": chunk, "launch_shape": env.launch_shape(),
+                       "step": "one fused rollout launch over an action batch [env_steps_per_step, envs, agents]",
+                       "env_steps_per_step": chunk, "steps_per_launch": chunk,
+                       "ms_per_env_step": elapsed * 1e3 / (args.steps * chunk),
+                       "launch_shape": env.launch_shape(),
                        "outputs": "full trajectory" + (" (no obs)" if args.no_obs else "")},
             "counters": counters,
             "device": {"name": props.name, "compute_units": props.multi_processor_count,

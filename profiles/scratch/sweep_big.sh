@@ -2,7 +2,7 @@
 mkdir -p gpurun_out/big
 run() { # name E chunk extra-env args...
   n=$1; E=$2; C=$3; shift 3
-  timeout -k 10 120 python bench.py --no-cpu-baseline --envs-per-gpu $E --chunk $C --steps $((C*8)) --warmup $C "$@" > gpurun_out/big/$n.json 2> gpurun_out/big/$n.err || { tail -3 gpurun_out/big/$n.err; exit 1; }
+  timeout -k 10 120 python bench.py --no-cpu-baseline --envs-per-gpu $E --chunk $C --steps 8 --warmup 1 "$@" > gpurun_out/big/$n.json 2> gpurun_out/big/$n.err || { tail -3 gpurun_out/big/$n.err; exit 1; }
 }
 for rep in 1 2; do
 for E in 8192 16384; do
