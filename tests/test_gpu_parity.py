@@ -351,7 +351,8 @@ def test_fused_greedy_rollout_with_autoreset_equals_oracle(oracle, ccx, cfg_name
 
 
 # ---- against the oracle at sizes the goldens do not reach -------------------------------------
-def _random_case(oracle, ccx, cfg_name, E, K, seed, shuffle, auto_reset, shape=None, p_absent=0.0):
+def _random_case(oracle, ccx, cfg_name, E, K, seed, shuffle, auto_reset, shape=None, p_absent=0.0,
+                 writers=0, throttle=0):
     from collectivecrossing_amd.reset import build_reset_pool, seeded_positions
 
     g = Golden(cfg_name)
@@ -367,6 +368,10 @@ def _random_case(oracle, ccx, cfg_name, E, K, seed, shuffle, auto_reset, shape=N
     env = ccx(g.config, E)
     if shape:
         env.set_launch_shape(*shape)
+    if writers:
+        env.set_writers(writers)
+    if throttle:
+        env.set_store_throttle(throttle)
     if auto_reset:
         pool = build_reset_pool(g.config, 7000 + seed, 257)
         ob.set_reset_pool(pool)
@@ -418,6 +423,28 @@ def test_fuzz_configs_at_batch_sizes_the_goldens_do_not_reach(oracle, ccx, name)
     k = FUZZ.index(name)
     _random_case(oracle, ccx, name, E=130 + 37 * k, K=70, seed=40 + k, shuffle=bool(k & 2), auto_reset=bool(k & 4),
                  p_absent=0.08 if k % 3 == 0 else 0.0)
+
+
+@pytest.mark.parametrize("seed", range(28))
+def test_random_batch_sizes_and_launch_shapes_equal_oracle(oracle, ccx, seed):
+    """API fuzz: random env counts (partial last tiles, slab strides that are not line multiples),
+    step counts, tile shapes, tiles per workgroup, writer counts and store throttles."""
+    rng = np.random.default_rng(1000 + seed)
+    name = ["g1_c1_random", "g7_n3_small", "g7_n5_odd", "g7_n12_constant_negative", "g3_c3_dense_simple_distance",
+            "g7_n50_padded_group", "g4_c5_all_at_dest_greedy_32_32", "g10_fuzz_05", "g10_fuzz_14",
+            "g10_fuzz_17"][seed % 10]
+    N = Golden(name).N
+    G = 1
+    while G < N:
+        G *= 2
+    lanes = int(rng.choice([0, 0, G, 64, G * max(1, (64 // G) // 2)]))
+    E = int(rng.choice([1, 2, 7, 31, 33, 64, 100, 255, 257, 600, int(rng.integers(1, 900))]))
+    if N >= 32:
+        E = min(E, 150)
+    _random_case(oracle, ccx, name, E=E, K=int(rng.integers(1, 70)), seed=seed, shuffle=bool(rng.integers(0, 2)),
+                 auto_reset=bool(rng.integers(0, 2)), shape=(lanes, int(rng.integers(0, 5))),
+                 p_absent=float(rng.choice([0.0, 0.1])), writers=int(rng.integers(0, 5)),
+                 throttle=int(rng.choice([0, -1, 3, 16, 40])))
 
 
 def test_full_size_c2_properties(ccx):
