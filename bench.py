@@ -167,6 +167,7 @@ def main() -> int:
     ap.add_argument("--writers", type=int, default=0, help="writer waves per env tile (0=auto)")
     ap.add_argument("--pool", type=int, default=4096, help="reset-pool entries (seeds 0..pool-1)")
     ap.add_argument("--throttle", type=int, default=0, help="stores a writer keeps in flight (0=auto, -1=off)")
+    ap.add_argument("--pace", type=int, default=0, help="ns per env-step (0=adaptive, -1=off)")
     ap.add_argument("--policy", default="random", choices=["random", "greedy"],
                     help="random = actions from a device tensor (the bench line); greedy = the "
                          "reference's GreedyPolicy(epsilon=0) evaluated inside the rollout kernel (BASELINE configs[4])")
@@ -205,6 +206,8 @@ def main() -> int:
         env.set_writers(args.writers)
     if args.throttle:
         env.set_store_throttle(args.throttle)
+    if args.pace:
+        env.set_step_pace(args.pace)
     env.make_reset_pool(0, args.pool, on_device=not os.environ.get("CCX_DIAG_LIB"))  # seeds 0..pool-1
     env.reset_from_pool()
 
@@ -288,7 +291,7 @@ def main() -> int:
                        "step": "one fused rollout launch over an action batch [env_steps_per_step, envs, agents]",
                        "env_steps_per_step": chunk, "steps_per_launch": chunk,
                        "ms_per_env_step": elapsed * 1e3 / (args.steps * chunk),
-                       "launch_shape": env.launch_shape(),
+                       "launch_shape": env.launch_shape(), "step_pace_ns": env.step_pace_ns(),
                        "outputs": "full trajectory" + (" (no obs)" if args.no_obs else "")},
             "counters": counters,
             "device": {"name": props.name, "compute_units": props.multi_processor_count,

@@ -296,6 +296,15 @@ class BatchedCollectiveCrossing:
     def set_store_throttle(self, max_stores_in_flight: int = 0) -> None:
         check(self._lib.ccx_set_store_throttle(self._h, max_stores_in_flight))
 
+    def set_step_pace(self, ns_per_env_step: int = 0) -> None:
+        """0 = adaptive (default), -1 = off, > 0 = fixed nanoseconds per env-step (``ccx_set_step_pace``)."""
+        check(self._lib.ccx_set_step_pace(self._h, int(ns_per_env_step)))
+
+    def step_pace_ns(self) -> float:
+        ns = C.c_float()
+        check(self._lib.ccx_get_step_pace(self._h, C.byref(ns)))
+        return float(ns.value)
+
     def launch_shape(self) -> dict[str, int]:
         v = [C.c_int32() for _ in range(4)]
         check(self._lib.ccx_get_launch_shape(self._h, *[C.byref(x) for x in v]))

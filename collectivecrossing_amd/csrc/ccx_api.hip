@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -60,6 +61,11 @@ struct ccx_handle {
     bool timing = false;                                       // record HIP events around launches
     int lanes_per_wave = 0, waves_per_block = 0, writers = 0;  // user overrides (0 = default)
     int store_throttle = 0;                                    // 0 = default, -1 = off, >0 = stores in flight
+    int step_pace_ns = 0;                                      // 0 = adaptive, -1 = off, >0 = fixed ns per env-step
+    uint32_t* pace_state = nullptr;                            // device: current pace (ticks x 256)
+    uint32_t pace_init_fp = 0;                                 // value to (re)start the controller from
+    bool pace_dirty = true;                                    // pace_state must be rewritten before a launch
+    int num_cus = 256;
     ccx::LaunchShape shape{};
     ccx::KParams kp{};
 };
@@ -163,8 +169,11 @@ void choose_shape(ccx_handle* h) {
     s.envs_per_wave = ew;
     s.waves_per_block = tpb;
     s.writers = writers;
+    // with step pacing (the default) the throttle is only a safety net against a collapse of the
+    // drain rate when the pace is too fast; without pacing it is the regulator (16, see above)
     s.store_throttle = h->store_throttle > 0 ? h->store_throttle
-                       : (h->store_throttle == 0 && small_tiles && writers == 1) ? 16 : 0;
+                       : (h->store_throttle == 0 && small_tiles && writers == 1)
+                             ? (h->step_pace_ns == -1 ? 16 : 48) : 0;
     s.num_blocks = (tiles + tpb - 1) / tpb;
 
     // LDS carve-up (see ccx_kernels.hip): [cell table][tiles][u16 obs table]
@@ -206,8 +215,24 @@ void choose_shape(ccx_handle* h) {
     k.off_ws = (uint32_t)off_ws; k.off_occ = (uint32_t)off_occ;
     k.occ_words = s.occ ? (uint32_t)(occ_bytes / 4u) : 0u;
     k.off_table = (uint32_t)(off_tiles + (size_t)tpb * tile_stride);
-    k._pad = 0;
     k.writer_vmcnt = (uint32_t)s.store_throttle;
+
+    // Step pacing (ccx_kernels.hip).  The schedule limits the rate at which the resident
+    // workgroups inject observation stores; its start value assumes a drain rate of 6.6 TB/s and the
+    // kernel retunes it after every long launch (bounds: 7.8 TB/s .. a sixth of the start rate).
+    (void)hipSetDevice(h->device);
+    int per_cu = ccx::rollout_blocks_per_cu(s, h->N);
+    if (per_cu < 1) per_cu = 1;
+    s.resident_blocks = std::min(s.num_blocks, per_cu * h->num_cus);
+    const double tile_bytes = (double)ew * h->N * (4.0 * (6 + 4 * h->N) + 10.0) + ew;
+    s.step_bytes = tile_bytes * tpb * s.resident_blocks;
+    auto to_fp = [](double ns) { double v = ns / 10.0 * 256.0; return (uint32_t)(v < 1.0 ? 1.0 : (v > 4.0e9 ? 4.0e9 : v)); };
+    k.pace_state = (h->step_pace_ns == -1) ? nullptr : h->pace_state;
+    k.pace_adapt = (h->step_pace_ns == 0) ? 1u : 0u;
+    k.pace_min_fp = to_fp(s.step_bytes / 7800.0);
+    k.pace_max_fp = to_fp(s.step_bytes / 1100.0);
+    h->pace_init_fp = h->step_pace_ns > 0 ? to_fp((double)h->step_pace_ns) : to_fp(s.step_bytes / 6600.0);
+    h->pace_dirty = true;
     k.r_dest = p.boarding_destination_reward; k.r_door = p.tram_door_reward;
     k.r_area = p.tram_area_reward; k.r_f = p.distance_penalty_factor;
     k.r_nogoal = p.no_goal_reward; k.r_pen = p.step_penalty;
@@ -255,6 +280,10 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     if (out.reward && (reinterpret_cast<uintptr_t>(out.reward) & 7u))
         return fail(CCX_EINVAL, "reward buffer must be 8-byte aligned");
     CCX_HIP(hipSetDevice(h->device));
+    if (h->pace_dirty) {   // (re)start the pace controller: new handle, new launch shape or new setting
+        CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state), (int)h->pace_init_fp, 1, h->stream));
+        h->pace_dirty = false;
+    }
     int rc = begin_timed(h);
     if (rc) return rc;
     hipError_t e = ccx::launch_rollout(h->shape, h->stream, h->kp, h->st, h->cell_info, actions,
@@ -328,6 +357,10 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     alloc((void**)&h->st.episode, (size_t)h->E * 4);
     alloc((void**)&h->counters, ccx::counter_words(h->E) * sizeof(unsigned long long));
     alloc((void**)&h->placement_scratch, en * 2);
+    alloc((void**)&h->pace_state, 2 * sizeof(uint32_t));
+    if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess ||
+        h->num_cus < 1)
+        h->num_cus = 256;
     const std::vector<unsigned long long> cell_tab = build_cell_table(*params);
     alloc((void**)&h->cell_info, cell_tab.size() * sizeof(unsigned long long));
     if (e == hipSuccess)
@@ -367,6 +400,7 @@ void ccx_destroy(ccx_handle* h) {
     (void)hipFree(h->st.step_count);
     (void)hipFree(h->st.episode);
     (void)hipFree(h->counters);
+    (void)hipFree(h->pace_state);
     (void)hipFree(h->cell_info);
     (void)hipFree(h->placement_scratch);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
@@ -638,6 +672,28 @@ int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight) {
         return fail(CCX_EINVAL, "max_stores_in_flight must be -1 (off), 0 (default) or 1..63");
     h->store_throttle = max_stores_in_flight;
     choose_shape(h);
+    return CCX_OK;
+}
+
+int ccx_set_step_pace(ccx_handle* h, int32_t ns_per_env_step) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if (ns_per_env_step < -1) return fail(CCX_EINVAL, "ns_per_env_step must be -1 (off), 0 (adaptive) or > 0");
+    h->step_pace_ns = ns_per_env_step;
+    choose_shape(h);
+    return CCX_OK;
+}
+
+int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {
+    if (!h || !ns_per_env_step) return fail(CCX_EINVAL, "NULL argument");
+    CCX_HIP(hipSetDevice(h->device));
+    uint32_t fp = h->pace_init_fp;
+    if (h->step_pace_ns == -1) {
+        fp = 0;
+    } else if (!h->pace_dirty) {
+        CCX_HIP(hipStreamSynchronize(h->stream));
+        CCX_HIP(hipMemcpy(&fp, h->pace_state, sizeof(fp), hipMemcpyDeviceToHost));
+    }
+    *ns_per_env_step = (float)((double)fp / 256.0 * 10.0);
     return CCX_OK;
 }
 

@@ -27,8 +27,12 @@ struct KParams {
     uint32_t off_ws, off_occ;            // within a tile: WSlot array, occupancy/proposal tables
     uint32_t occ_words;                  // 32-bit words of one tile's occupancy+proposal tables
     uint32_t off_table;                  // u16 obs address table
-    uint32_t _pad;
+    uint32_t pace_adapt;                 // 1: the kernel retunes *pace_state after every long launch
     uint32_t writer_vmcnt;               // >0: a writer starts a step only with <= this many of its stores in flight
+    // step pacing (rollouts that write observations): every tile starts env-step s no earlier than
+    // t0 + s * pace on the 100 MHz s_memrealtime clock; pace = *pace_state in ticks x 256 (0 = off)
+    uint32_t* pace_state;
+    uint32_t pace_min_fp, pace_max_fp;
     double r_dest, r_door, r_area, r_f, r_nogoal, r_pen;
     long long env_offset;                // global index of env 0 (sharding)
     long long pool_size;                 // reset-pool entries (0 = none)
@@ -64,6 +68,8 @@ struct LaunchShape {
     int waves_per_block;  // env tiles per block (each: 1 sim wave + `writers` writer waves)
     int writers;
     int store_throttle;   // max stores a writer keeps in flight when it starts a step (0 = unlimited)
+    int resident_blocks;  // workgroups of the rollout kernel the device holds at once (<= num_blocks)
+    double step_bytes;    // bytes the resident workgroups write per env-step
     int occ;              // 1: occupancy-table conflict masks fit in LDS
     int num_blocks;
     size_t lds_bytes;        // rollout kernel: cell table + per-wave tiles + obs table
@@ -75,6 +81,7 @@ hipError_t launch_rollout(const LaunchShape& ls, hipStream_t stream, const KPara
                           const uint8_t* actions, const uint8_t* order, int K,
                           int auto_reset, const uint8_t* pool, const KOut& out,
                           unsigned long long* counters, int policy = 0, uint8_t* actions_out = nullptr);
+int rollout_blocks_per_cu(const LaunchShape& ls, int agents);
 hipError_t launch_reduce_counters(hipStream_t stream, unsigned long long* counters, int slots);
 hipError_t launch_observe(const LaunchShape& ls, hipStream_t stream, const KParams& p,
                           const KState& st, float* obs);

@@ -563,6 +563,14 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     };
     if (!policy) fetch_actions(0);
 
+    // ---- step pacing: a smooth, absolute schedule for the output stream ----------
+    uint32_t pace = 0;
+    unsigned long long pace_t0 = 0, pace_due = 0;   // ticks, ticks x 256 since t0
+    if (want_obs && p.pace_state && K >= 16) {   // (short launches: not worth the load)
+        pace = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile const uint32_t*>(p.pace_state));
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pace_t0)::"memory");
+    }
+
     int s = 0;
     for (int s0 = 0; s0 < K; s0 += kActBatch) {
         // the burst issued one batch ago is consumed here: ONE vmcnt wait per kActBatch steps.
@@ -586,6 +594,16 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
 
         uint32_t acur = apk[0];
         for (int d = 0; d < dmax; ++d, ++s) {
+            if (pace) {   // env-step s is due at t0 + s * pace; a late tile does not wait (it catches up)
+                const unsigned long long due = pace_t0 + (pace_due >> 8);
+                pace_due += pace;
+                while (true) {
+                    unsigned long long now;
+                    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+                    if ((long long)(due - now) <= 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
             if (d == 8) acur = apk[1];
             uint32_t a = acur & 0xFu;
             acur >>= 4;
@@ -818,6 +836,26 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     }
     CCX_STAMP_FLUSH(ctr, 0);
 
+    // ---- pace control: ONE wave retunes the common pace for the next launch.  Late by more than
+    // 1.5 % of the schedule = the memory side could not drain the stream at this rate: slow down by
+    // half the overshoot (0.5 % .. 5 %); on time: probe 0.4 % faster.
+    if (pace && p.pace_adapt && tile == 0 && K >= 64) {
+        unsigned long long now;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+        const unsigned long long elapsed_fp = (now - pace_t0) << 8, planned_fp = (unsigned long long)K * pace;
+        uint32_t next = pace;
+        if (elapsed_fp > planned_fp + (planned_fp >> 6)) {
+            uint32_t inc = (uint32_t)((elapsed_fp - planned_fp) / (2ull * (unsigned long long)K));
+            const uint32_t lo = pace / 200u, hi = pace / 20u;
+            inc = inc < lo ? lo : (inc > hi ? hi : inc);
+            next = pace + inc;
+        } else {
+            next = pace - (pace >> 8);
+        }
+        next = next < p.pace_min_fp ? p.pace_min_fp : (next > p.pace_max_fp ? p.pace_max_fp : next);
+        if (lane == 0) *p.pace_state = next;
+    }
+
     // ---- registers -> state ------------------------------------------------------------------
     if (valid) {
         *fx = (int)((ilo >> 16) & 0xFFu);
@@ -975,6 +1013,41 @@ static hipError_t launch_rollout_g(const LaunchShape& ls, hipStream_t stream, co
     default: CCX_GO(false, false, false);
     }
 #undef CCX_GO
+}
+
+template <int GLOG>
+static int blocks_per_cu_g(const LaunchShape& ls, bool pair) {
+    const int threads = 64 * ls.waves_per_block * (1 + ls.writers);
+    int n = 0;
+    hipError_t e = hipSuccess;
+#define CCX_OCCQ(P_, C_)                                                                          \
+    do {                                                                                          \
+        const void* f = reinterpret_cast<const void*>(&rollout_kernel<GLOG, P_, true, C_>);       \
+        if (ls.lds_bytes > 60 * 1024)                                                             \
+            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, threads, ls.lds_bytes);           \
+    } while (0)
+    if (pair && ls.occ) CCX_OCCQ(true, true);
+    else if (pair) CCX_OCCQ(true, false);
+    else if (ls.occ) CCX_OCCQ(false, true);
+    else CCX_OCCQ(false, false);
+#undef CCX_OCCQ
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+// workgroups of the rollout kernel (with outputs) one CU holds at once; 0 = unknown
+int rollout_blocks_per_cu(const LaunchShape& ls, int agents) {
+    const bool pair = (agents % 2) == 0;
+    switch (ls.glog) {
+    case 0: return blocks_per_cu_g<0>(ls, pair);
+    case 1: return blocks_per_cu_g<1>(ls, pair);
+    case 2: return blocks_per_cu_g<2>(ls, pair);
+    case 3: return blocks_per_cu_g<3>(ls, pair);
+    case 4: return blocks_per_cu_g<4>(ls, pair);
+    case 5: return blocks_per_cu_g<5>(ls, pair);
+    default: return blocks_per_cu_g<6>(ls, pair);
+    }
 }
 
 template <int GLOG>

@@ -257,6 +257,15 @@ int ccx_set_writers(ccx_handle* h, int32_t writers_per_tile);
  * (0 = library default, -1 = unlimited, 1..63).  Many small env tiles oversubscribe the HBM write
  * queues; bounding the in-flight stores raises the sustained write rate. */
 int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight);
+/* Step pacing of rollouts that write observations: every env tile starts env-step s no earlier than
+ * t0 + s * pace on the GPU's 100 MHz clock, which turns the output into a smooth stream at (just under)
+ * the HBM drain rate instead of bursts that oversubscribe the write queues.
+ *   0  = adaptive (default): starts from an assumed 6.6 TB/s and is retuned by the kernel after every
+ *        launch of >= 64 steps (late => slower, on time => 0.4 % faster)
+ *   -1 = off;   > 0 = fixed pace in nanoseconds per env-step.
+ * ccx_get_step_pace returns the pace in effect (synchronises).  Results never depend on it. */
+int ccx_set_step_pace(ccx_handle* h, int32_t ns_per_env_step);
+int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step);
 /* the writers per tile and the store throttle in effect (0 = unlimited) */
 int ccx_get_writer_shape(ccx_handle* h, int32_t* writers_per_tile, int32_t* max_stores_in_flight);
 int ccx_get_launch_shape(ccx_handle* h, int32_t* lanes_per_wave, int32_t* waves_per_block,

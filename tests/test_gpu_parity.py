@@ -117,6 +117,49 @@ def test_store_throttle_does_not_change_results(ccx, name, writers, throttle):
     env.close()
 
 
+@pytest.mark.parametrize("name", ["g1_c1_random", "g3_c3_dense_shuffled", "g7_n50_padded_group"])
+@pytest.mark.parametrize("pace", [0, -1, 40, 3000])
+def test_step_pacing_does_not_change_results(ccx, name, pace):
+    """Step pacing only delays when a tile starts an env-step (adaptive, off, far too fast, slow)."""
+    g = Golden(name)
+    env = ccx(g.config, g.E)
+    env.set_step_pace(pace)
+    if pace > 0:
+        assert abs(env.step_pace_ns() - pace) <= 0.05
+    if pace == -1:
+        assert env.step_pace_ns() == 0.0
+    env.set_state(**g.init_state())
+    res = env.rollout(g["actions"], g["order"])
+    _check_rollout_vs_golden(g, res, env.get_state())
+    if pace > 0:
+        assert abs(env.step_pace_ns() - pace) <= 0.05      # a fixed pace is never retuned
+    with pytest.raises(Exception):
+        env.set_step_pace(-2)
+    env.close()
+
+
+def test_adaptive_pace_settles_near_the_drain_rate(ccx):
+    """C2-sized rollouts: after a few launches the adaptive pace sits between the controller's bounds
+    and within a factor of two of bytes-per-step / 8 TB/s."""
+    import torch
+
+    g = Golden("g1_c1_random")
+    E, K = 4096, 128
+    env = ccx(g.config, E)
+    env.make_reset_pool(0, 512, on_device=True)
+    env.reset_from_pool()
+    acts = torch.randint(0, 5, (K, E, g.N), dtype=torch.uint8, device=env.device)
+    traj = env.alloc_rollout(K)
+    start = env.step_pace_ns()
+    for _ in range(12):
+        env.rollout(acts, auto_reset=True, out=traj)
+    settled = env.step_pace_ns()
+    floor_ns = E * g.N * (4 * (6 + 4 * g.N) + 10) / 8000.0      # bytes per env-step / (8 TB/s in B/ns)
+    assert start > 0 and settled != start
+    assert floor_ns * 0.9 <= settled <= floor_ns * 2.0, (start, settled, floor_ns)
+    env.close()
+
+
 def test_huge_grid_uses_the_all_pairs_fallback_and_big_lds(oracle, ccx):
     """100x100 grid: the occupancy tables do not fit in LDS (all-pairs path) and the cell table
     alone needs > 64 KiB of dynamic LDS.  Checked against the oracle, with shuffled move order."""
