@@ -218,7 +218,7 @@ void choose_shape(ccx_handle* h) {
     k.writer_vmcnt = (uint32_t)s.store_throttle;
 
     // Step pacing (ccx_kernels.hip).  The schedule limits the rate at which the resident
-    // workgroups inject observation stores; its start value assumes a drain rate of 6.6 TB/s and the
+    // workgroups inject observation stores; its start value assumes a drain rate of 6.8 TB/s and the
     // kernel retunes it after every long launch (bounds: 7.8 TB/s .. a sixth of the start rate).
     (void)hipSetDevice(h->device);
     int per_cu = ccx::rollout_blocks_per_cu(s, h->N);
@@ -231,7 +231,7 @@ void choose_shape(ccx_handle* h) {
     k.pace_adapt = (h->step_pace_ns == 0) ? 1u : 0u;
     k.pace_min_fp = to_fp(s.step_bytes / 7800.0);
     k.pace_max_fp = to_fp(s.step_bytes / 1100.0);
-    h->pace_init_fp = h->step_pace_ns > 0 ? to_fp((double)h->step_pace_ns) : to_fp(s.step_bytes / 6600.0);
+    h->pace_init_fp = h->step_pace_ns > 0 ? to_fp((double)h->step_pace_ns) : to_fp(s.step_bytes / 6800.0);
     h->pace_dirty = true;
     k.r_dest = p.boarding_destination_reward; k.r_door = p.tram_door_reward;
     k.r_area = p.tram_area_reward; k.r_f = p.distance_penalty_factor;

@@ -260,7 +260,7 @@ int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight);
 /* Step pacing of rollouts that write observations: every env tile starts env-step s no earlier than
  * t0 + s * pace on the GPU's 100 MHz clock, which turns the output into a smooth stream at (just under)
  * the HBM drain rate instead of bursts that oversubscribe the write queues.
- *   0  = adaptive (default): starts from an assumed 6.6 TB/s and is retuned by the kernel after every
+ *   0  = adaptive (default): starts from an assumed 6.8 TB/s and is retuned by the kernel after every
  *        launch of >= 64 steps (late => slower, on time => 0.4 % faster)
  *   -1 = off;   > 0 = fixed pace in nanoseconds per env-step.
  * ccx_get_step_pace returns the pace in effect (synchronises).  Results never depend on it. */
