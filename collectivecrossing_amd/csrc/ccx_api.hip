@@ -153,9 +153,10 @@ void choose_shape(ccx_handle* h) {
     // writer waves per tile: enough that a writer handles <= ~6 store iterations per step
     const int units = ew * h->N * (3 + 2 * h->N);
     const int n4 = (h->N % 2 == 0) ? units / 2 : units;
-    // Small tiles (<= 12 store iterations per step, e.g. C2's 9.5): ONE writer that keeps at most 16
-    // stores in flight -- measured 0.90 us/step vs 0.98-1.00 unthrottled with 1-2 writers (many small
-    // tiles oversubscribe the HBM write queues).  Larger tiles: 2-3 writers, no throttle (no effect).
+    // Small tiles (<= 12 store iterations per step, e.g. C2's 9.5): ONE writer wave whose stores in
+    // flight are bounded (many small tiles oversubscribe the HBM write queues; the bound is the
+    // regulator when step pacing is off and a safety net when it is on).
+    // Larger tiles: 2-3 writers, no throttle (measured: no effect).
     const bool small_tiles = n4 <= 64 * 12;
     int writers = h->writers > 0 ? h->writers : (n4 > 64 * 24 ? 3 : small_tiles ? 1 : 2);
     if (writers > 7) writers = 7;
