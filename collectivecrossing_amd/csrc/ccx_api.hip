@@ -65,6 +65,7 @@ struct ccx_handle {
     uint32_t* pace_state = nullptr;                            // device: current pace (ticks x 256)
     uint32_t pace_init_fp = 0;                                 // value to (re)start the controller from
     bool pace_dirty = true;                                    // pace_state must be rewritten before a launch
+    uint32_t pace_slot = 0;                                    // slot of pace_state the next launch reads
     int num_cus = 256;
     ccx::LaunchShape shape{};
     ccx::KParams kp{};
@@ -230,6 +231,8 @@ void choose_shape(ccx_handle* h) {
     auto to_fp = [](double ns) { double v = ns / 10.0 * 256.0; return (uint32_t)(v < 1.0 ? 1.0 : (v > 4.0e9 ? 4.0e9 : v)); };
     k.pace_state = (h->step_pace_ns == -1) ? nullptr : h->pace_state;
     k.pace_adapt = (h->step_pace_ns == 0) ? 1u : 0u;
+    const int tiles_total = (h->E + ew - 1) / ew;
+    k.pace_sample = (uint32_t)std::max(1, tiles_total / 16);
     k.pace_min_fp = to_fp(s.step_bytes / 7800.0);
     k.pace_max_fp = to_fp(s.step_bytes / 1100.0);
     h->pace_init_fp = h->step_pace_ns > 0 ? to_fp((double)h->step_pace_ns) : to_fp(s.step_bytes / 6800.0);
@@ -282,14 +285,18 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
         return fail(CCX_EINVAL, "reward buffer must be 8-byte aligned");
     CCX_HIP(hipSetDevice(h->device));
     if (h->pace_dirty) {   // (re)start the pace controller: new handle, new launch shape or new setting
-        CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state), (int)h->pace_init_fp, 1, h->stream));
+        CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state + h->pace_slot),
+                                  (int)h->pace_init_fp, 1, h->stream));
         h->pace_dirty = false;
     }
+    h->kp.pace_slot = h->pace_slot;
     int rc = begin_timed(h);
     if (rc) return rc;
     hipError_t e = ccx::launch_rollout(h->shape, h->stream, h->kp, h->st, h->cell_info, actions,
                                        order, K, auto_reset, h->pool, out, h->counters, policy, actions_out);
     if (e != hipSuccess) return fail(CCX_EHIP, "rollout kernel launch failed: %s", hipGetErrorString(e));
+    // the kernel collected the votes for the next pace in the other slot (same condition as in the kernel)
+    if (h->kp.pace_state && h->kp.pace_adapt && out.obs && K >= 64) h->pace_slot ^= 1u;
     return end_timed(h);
 }
 
@@ -692,7 +699,7 @@ int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {
         fp = 0;
     } else if (!h->pace_dirty) {
         CCX_HIP(hipStreamSynchronize(h->stream));
-        CCX_HIP(hipMemcpy(&fp, h->pace_state, sizeof(fp), hipMemcpyDeviceToHost));
+        CCX_HIP(hipMemcpy(&fp, h->pace_state + h->pace_slot, sizeof(fp), hipMemcpyDeviceToHost));
     }
     *ns_per_env_step = (float)((double)fp / 256.0 * 10.0);
     return CCX_OK;

@@ -567,7 +567,10 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     uint32_t pace = 0;
     unsigned long long pace_t0 = 0, pace_due = 0;   // ticks, ticks x 256 since t0
     if (want_obs && p.pace_state && K >= 16) {   // (short launches: not worth the load)
-        pace = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile const uint32_t*>(p.pace_state));
+        pace = __builtin_amdgcn_readfirstlane(
+            *reinterpret_cast<volatile const uint32_t*>(p.pace_state + p.pace_slot));
+        if (p.pace_adapt && K >= 64 && tile == 0 && lane == 0)
+            p.pace_state[p.pace_slot ^ 1u] = 0u;   // the votes of this launch are collected here
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pace_t0)::"memory");
     }
 
@@ -836,10 +839,11 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     }
     CCX_STAMP_FLUSH(ctr, 0);
 
-    // ---- pace control: ONE wave retunes the common pace for the next launch.  Late by more than
-    // 1.5 % of the schedule = the memory side could not drain the stream at this rate: slow down by
-    // half the overshoot (0.5 % .. 5 %); on time: probe 0.4 % faster.
-    if (pace && p.pace_adapt && tile == 0 && K >= 64) {
+    // ---- pace control: a sample of the tiles (spread over the grid, so over every round of
+    // workgroups) votes on the common pace of the next launch; the slowest vote wins (atomicMax).
+    // Late by more than 1.5 % of the schedule = the memory side could not drain the stream at this
+    // rate: slow down by half the overshoot (0.5 % .. 5 %); on time: probe 0.4 % faster.
+    if (pace && p.pace_adapt && K >= 64 && (uint32_t)tile % p.pace_sample == 0u) {
         unsigned long long now;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
         const unsigned long long elapsed_fp = (now - pace_t0) << 8, planned_fp = (unsigned long long)K * pace;
@@ -853,7 +857,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             next = pace - (pace >> 8);
         }
         next = next < p.pace_min_fp ? p.pace_min_fp : (next > p.pace_max_fp ? p.pace_max_fp : next);
-        if (lane == 0) *p.pace_state = next;
+        if (lane == 0) atomicMax(&p.pace_state[p.pace_slot ^ 1u], next);
     }
 
     // ---- registers -> state ------------------------------------------------------------------
