@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/sweep
 for E in 64 256 1024 2048 4096 8192 16384 65536; do
   C=500; [ $E -ge 16384 ] && C=100; [ $E -ge 65536 ] && C=40
-  timeout -k 10 120 python bench.py --no-cpu-baseline --envs-per-gpu $E --chunk $C --steps 8 --warmup 1 > gpurun_out/sweep/e$E.json 2> gpurun_out/sweep/e$E.err || { tail -3 gpurun_out/sweep/e$E.err; exit 1; }
+  timeout -k 10 120 python bench.py --no-cpu-baseline --envs-per-gpu $E --chunk $C --steps 16 --warmup 12 > gpurun_out/sweep/e$E.json 2> gpurun_out/sweep/e$E.err || { tail -3 gpurun_out/sweep/e$E.err; exit 1; }
 done
 python - <<PY
 import json,glob
