@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CCX_ABI_VERSION 1
+#define CCX_ABI_VERSION 2
 
 typedef enum ccx_status {
     CCX_OK = 0,
