@@ -29,7 +29,9 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.ccx_abi_version() == 1
+    from collectivecrossing_amd import _abi
+
+    assert lib.ccx_abi_version() == _abi.ABI_VERSION == 2
     assert lib.ccx_obs_len(8) == 38 and lib.ccx_obs_len(3) == 18
     assert b"gfx950" in lib.ccx_build_info()
 
