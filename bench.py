@@ -149,9 +149,20 @@ def cpu_baseline(config, n_agents: int, seconds_target: float = 12.0) -> dict:
             "sample": (f"oracle/ccx_oracle.c ccxo_rollout, same config/outputs (full trajectory), "
                        f"{cores} threads x {reps} x ({E_t} envs x {K} steps) in {dtm:.1f}s; "
                        f"1 thread: {reps1} x ({E_t} x {K}) in {dt1:.1f}s"),
-            "reference_python_note": ("the Python reference itself steps ~2.4e3 env-steps/s on one "
-                                      "core of the build container (SURVEY 6 probe); it cannot "
-                                      "travel to the GPU box")}
+            "reference_python": reference_python_speed()}
+
+
+def reference_python_speed():
+    """The pure-Python reference cannot travel to the GPU box; its speed was recorded in the build
+    container by tests/golden/ref_speed.py (data file, read here for the record only)."""
+    f = ROOT / "profiles" / "r01_reference_python_speed.json"
+    try:
+        d = json.loads(f.read_text())
+        return {"value": d["C1_12x8_5+3"]["env_steps_per_sec_one_core"], "unit": "env-steps/s", "cores": 1,
+                "where": "build container (not the GPU box), tests/golden/ref_speed.py, time inside env.step only",
+                "config": "BASELINE configs[0] geometry = the per-env workload of this bench"}
+    except Exception:
+        return None
 
 
 def main() -> int:
