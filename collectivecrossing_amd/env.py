@@ -150,7 +150,8 @@ class CollectiveCrossingEnv(_Base):
 
     metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 4}
 
-    def __init__(self, config: CollectiveCrossingConfig, device: int | str | None = None):
+    def __init__(self, config: CollectiveCrossingConfig, device: int | str | None = None, *,
+                 _host_view: bool = False):
         self._config = config
         self._tram_boundaries = calculate_tram_boundaries(config)
         self._action_to_direction = ACTION_TO_DIRECTION
@@ -181,7 +182,9 @@ class CollectiveCrossingEnv(_Base):
             if fn.kernel_mode is None:
                 raise NotImplementedError(f"user-defined {what} strategies change the state transition and "
                                           "are not supported by the GPU step")
-        self._batch = BatchedCollectiveCrossing(gpu_config, 1, device=device)
+        # _host_view: no GPU handle -- only the host mirror and the predicates / strategy objects on
+        # it (inspect recorded states, drive host-side policies); reset() and step() need the GPU
+        self._batch = None if _host_view else BatchedCollectiveCrossing(gpu_config, 1, device=device)
         self.np_random: np.random.Generator | None = None
         self._window = None
         self._clock = None
@@ -239,7 +242,20 @@ class CollectiveCrossingEnv(_Base):
             self.observation_space = self._observation_spaces[self._ids[0]]
 
     # ------------------------------------------------------------------ state sync
+    @classmethod
+    def host_view(cls, config: CollectiveCrossingConfig) -> "CollectiveCrossingEnv":
+        """An env object WITHOUT a GPU handle: the agent views, geometry predicates and strategy
+        objects work on the host mirror (set states through ``env._agents[...]``); ``reset`` /
+        ``step`` raise.  Used to evaluate host-side policies on recorded states."""
+        return cls(config, _host_view=True)
+
+    def _need_gpu(self) -> None:
+        if self._batch is None:
+            raise RuntimeError("this CollectiveCrossingEnv is a host view (no GPU handle): reset() and "
+                               "step() are unavailable")
+
     def _upload(self) -> None:
+        self._need_gpu()
         m = self._mirror
         if m.dirty:
             self._batch.set_state(x=m.x, y=m.y, active=m.active, terminated=m.terminated,
@@ -258,6 +274,7 @@ class CollectiveCrossingEnv(_Base):
     # ------------------------------------------------------------------ reset / step
     def reset(self, *, seed: int | None = None, options: dict | None = None):
         """Seeded rejection-sampled placement (collectivecrossing.py:91-159), bit-identical."""
+        self._need_gpu()
         if seed is not None or self.np_random is None:
             self.np_random = make_generator(seed)        # gymnasium.Env.reset(seed=...)
         pos = sample_initial_positions(self._config, self.np_random)
@@ -320,8 +337,9 @@ class CollectiveCrossingEnv(_Base):
         self._step_out_ref = C.byref(self._step_out)
 
     def step(self, action_dict):
-        """One tick (collectivecrossing.py:161-261) on the GPU: one H2D copy (actions + move
-        order), one ``ccx_step`` launch, one D2H copy (obs + rewards + flag bytes)."""
+        """One tick (collectivecrossing.py:161-261) on the GPU: one ``ccx_step`` launch that reads
+        the actions / move order from and writes obs + rewards + flag bytes to pinned host memory
+        (zero-copy; two staging copies instead with CCX_ENV_STAGED=1), one stream sync."""
         import ctypes as C
 
         ids = self._ids

@@ -265,20 +265,20 @@ def run_random(name, cfg, seeds, K, shuffle=False, p_absent=0.0, act_done=True):
     rec.save(name, seeds=np.asarray(seeds, np.int64))
 
 
-def run_greedy(name, cfg, seeds, K, policy="greedy"):
-    """reset(seed) then the reference's GreedyPolicy / WaitingPolicy (epsilon=0) for live agents in
-    index order."""
+def run_greedy(name, cfg, seeds, K, policy="greedy", epsilon=0.0):
+    """reset(seed) then the reference's GreedyPolicy / WaitingPolicy (epsilon=0 unless given; one
+    policy object = one RandomState(42) per env) for live agents in index order."""
     from baseline_policies import GreedyPolicy, WaitingPolicy
     rec = Recorder(cfg, len(seeds), K)
     for e, seed in enumerate(seeds):
         env = rec.envs[e]
         obs, _ = env.reset(seed=int(seed))
         rec.snapshot_init(e)
-        pol = (GreedyPolicy if policy == "greedy" else WaitingPolicy)(randomness_factor=0.0, seed=42)
+        pol = (GreedyPolicy if policy == "greedy" else WaitingPolicy)(randomness_factor=epsilon, seed=42)
         for s in range(K):
             acts = {aid: int(pol.get_action(aid, None, env)) for aid in env.agents}
             rec.step(s, e, acts)
-    rec.save(name, seeds=np.asarray(seeds, np.int64))
+    rec.save(name, seeds=np.asarray(seeds, np.int64), **({"epsilon": np.float64(epsilon)} if epsilon else {}))
 
 
 def run_scenarios(name, cfg, scenarios):
@@ -505,6 +505,13 @@ def main() -> int:
         cfg = dict(cfg_fuzz(i), truncated_config=dict(truncated_function="max_steps", max_steps=70))
         pol = "waiting" if i % 3 == 2 else "greedy"
         run_greedy(f"g10_fuzz_{pol}_{i:02d}", cfg, seeds=[900 + 2 * i, 901 + 2 * i], K=74, policy=pol)
+    # G11: epsilon > 0 -- the policies' RandomState(42) stream decides when and what to randomise
+    run_greedy("g11_epsilon_policy_g_c1", cfg_c1(), seeds=range(1100, 1104), K=110, policy="greedy", epsilon=0.3)
+    run_greedy("g11_epsilon_policy_w_small", cfg_small(
+        terminated_config=dict(terminated_function="all_at_destination")), seeds=range(1110, 1116), K=56,
+        policy="waiting", epsilon=0.2)
+    run_greedy("g11_epsilon_policy_g_fuzz", dict(cfg_fuzz(25), truncated_config=dict(
+        truncated_function="max_steps", max_steps=70)), seeds=[1120, 1121], K=74, policy="greedy", epsilon=0.5)
     return 0
 
 

@@ -366,3 +366,41 @@ def test_host_device_pointer_rejects_pageable_memory(Env):
     rc = b._lib.ccx_host_device_pointer(b._h, C.c_void_p(pageable.ctypes.data), C.byref(out))
     assert rc != 0 and b"page-locked" in b._lib.ccx_last_error()
     env.close()
+
+
+@pytest.mark.parametrize("policy_name", ["greedy", "waiting"])
+def test_reference_demo_loop_with_the_host_policy_classes(Env, policy_name):
+    """scripts/run_greedy_policy_demo.py:67-109 / run_waiting_policy_demo.py: policy.get_action per
+    live agent, env.step, until __all__ -- through the dict API on the GPU, and the same episode
+    from the fused on-device policy rollout."""
+    from collectivecrossing_amd import baseline_policies as bp
+    from collectivecrossing_amd.batched import BatchedCollectiveCrossing
+    from collectivecrossing_amd.params import agent_ids
+
+    cfg = _cfg(num_boarding_agents=3, num_exiting_agents=2, tram_door_left=3, tram_door_right=5)
+    ids = agent_ids(cfg)
+    env = Env(config=cfg)
+    obs, _ = env.reset(seed=7)
+    start = np.array([env._agents[a].position for a in ids])
+    policy = (bp.create_greedy_policy if policy_name == "greedy" else bp.create_waiting_policy)(0.0)
+    taken, rewards_seen = [], []
+    for _ in range(100):
+        acts = {a: policy.get_action(a, obs[a], env) for a in env.agents}
+        row = np.full(len(ids), 255, np.uint8)
+        for a, v in acts.items():
+            row[ids.index(a)] = v
+        taken.append(row)
+        obs, rew, term, trunc, _ = env.step(acts)
+        rewards_seen.append(rew)
+        if term["__all__"] or trunc["__all__"]:
+            break
+    assert term["__all__"] or trunc["__all__"]    # (head-on greedy agents may deadlock at a one-cell door)
+    batch = BatchedCollectiveCrossing(cfg, 1)
+    batch.set_state(x=start[None, :, 0], y=start[None, :, 1])
+    res, fused_actions = batch.rollout_greedy(len(taken), policy=policy_name)
+    np.testing.assert_array_equal(fused_actions.cpu().numpy()[:, 0], np.stack(taken))
+    last = res.reward.cpu().numpy()[-1, 0]
+    for a, r in rewards_seen[-1].items():
+        assert r == last[ids.index(a)]
+    batch.close()
+    env.close()
