@@ -231,8 +231,7 @@ void choose_shape(ccx_handle* h) {
     auto to_fp = [](double ns) { double v = ns / 10.0 * 256.0; return (uint32_t)(v < 1.0 ? 1.0 : (v > 4.0e9 ? 4.0e9 : v)); };
     k.pace_state = (h->step_pace_ns == -1) ? nullptr : h->pace_state;
     k.pace_adapt = (h->step_pace_ns == 0) ? 1u : 0u;
-    const int tiles_total = (h->E + ew - 1) / ew;
-    k.pace_sample = (uint32_t)std::max(1, tiles_total / 16);
+    k._pad = 0;
     k.pace_min_fp = to_fp(s.step_bytes / 7800.0);
     k.pace_max_fp = to_fp(s.step_bytes / 1100.0);
     h->pace_init_fp = h->step_pace_ns > 0 ? to_fp((double)h->step_pace_ns) : to_fp(s.step_bytes / 6800.0);
@@ -285,6 +284,7 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
         return fail(CCX_EINVAL, "reward buffer must be 8-byte aligned");
     CCX_HIP(hipSetDevice(h->device));
     if (h->pace_dirty) {   // (re)start the pace controller: new handle, new launch shape or new setting
+        CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state), 0, 4, h->stream));   // floor = 0
         CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state + h->pace_slot),
                                   (int)h->pace_init_fp, 1, h->stream));
         h->pace_dirty = false;
@@ -365,7 +365,7 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     alloc((void**)&h->st.episode, (size_t)h->E * 4);
     alloc((void**)&h->counters, ccx::counter_words(h->E) * sizeof(unsigned long long));
     alloc((void**)&h->placement_scratch, en * 2);
-    alloc((void**)&h->pace_state, 2 * sizeof(uint32_t));
+    alloc((void**)&h->pace_state, 4 * sizeof(uint32_t));
     if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess ||
         h->num_cus < 1)
         h->num_cus = 256;
@@ -699,7 +699,9 @@ int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {
         fp = 0;
     } else if (!h->pace_dirty) {
         CCX_HIP(hipStreamSynchronize(h->stream));
-        CCX_HIP(hipMemcpy(&fp, h->pace_state + h->pace_slot, sizeof(fp), hipMemcpyDeviceToHost));
+        uint32_t st[4];
+        CCX_HIP(hipMemcpy(st, h->pace_state, sizeof(st), hipMemcpyDeviceToHost));
+        fp = st[h->pace_slot] > st[2] ? st[h->pace_slot] : st[2];
     }
     *ns_per_env_step = (float)((double)fp / 256.0 * 10.0);
     return CCX_OK;

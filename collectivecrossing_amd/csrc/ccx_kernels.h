@@ -31,9 +31,9 @@ struct KParams {
     uint32_t writer_vmcnt;               // >0: a writer starts a step only with <= this many of its stores in flight
     // step pacing (rollouts that write observations): every tile starts env-step s no earlier than
     // t0 + s * pace on the 100 MHz s_memrealtime clock; pace = *pace_state in ticks x 256 (0 = off)
-    uint32_t* pace_state;                // two slots: [pace_slot] is read, [pace_slot ^ 1] collects the next pace
+    uint32_t* pace_state;                // [pace_slot] is read, [pace_slot ^ 1] collects the votes, [2] = floor
     uint32_t pace_min_fp, pace_max_fp;
-    uint32_t pace_slot, pace_sample;     // tiles with index % pace_sample == 0 vote on the next pace
+    uint32_t pace_slot, _pad;
     double r_dest, r_door, r_area, r_f, r_nogoal, r_pen;
     long long env_offset;                // global index of env 0 (sharding)
     long long pool_size;                 // reset-pool entries (0 = none)

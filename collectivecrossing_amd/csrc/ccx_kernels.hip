@@ -564,13 +564,19 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     if (!policy) fetch_actions(0);
 
     // ---- step pacing: a smooth, absolute schedule for the output stream ----------
-    uint32_t pace = 0;
+    uint32_t pace = 0, pace_floor = 0;
     unsigned long long pace_t0 = 0, pace_due = 0;   // ticks, ticks x 256 since t0
     if (want_obs && p.pace_state && K >= 16) {   // (short launches: not worth the load)
-        pace = __builtin_amdgcn_readfirstlane(
-            *reinterpret_cast<volatile const uint32_t*>(p.pace_state + p.pace_slot));
-        if (p.pace_adapt && K >= 64 && tile == 0 && lane == 0)
-            p.pace_state[p.pace_slot ^ 1u] = 0u;   // the votes of this launch are collected here
+        // pace_state: [0], [1] = the pace slots (one is read, the other collects this launch's votes),
+        // [2] = floor: the pace just above the last collapse, decaying by 0.1 % per launch
+        const uint32_t voted = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + p.pace_slot);
+        const uint32_t floor_fp = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + 2);
+        pace = __builtin_amdgcn_readfirstlane(voted > floor_fp ? voted : floor_fp);
+        pace_floor = __builtin_amdgcn_readfirstlane(floor_fp);
+        if (p.pace_adapt && K >= 64 && tile == 0 && lane == 0) {
+            p.pace_state[p.pace_slot ^ 1u] = 0u;               // the votes of this launch are collected here
+            p.pace_state[2] = floor_fp - (floor_fp >> 10);
+        }
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pace_t0)::"memory");
     }
 
@@ -839,25 +845,37 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     }
     CCX_STAMP_FLUSH(ctr, 0);
 
-    // ---- pace control: a sample of the tiles (spread over the grid, so over every round of
-    // workgroups) votes on the common pace of the next launch; the slowest vote wins (atomicMax).
-    // Late by more than 1.5 % of the schedule = the memory side could not drain the stream at this
-    // rate: slow down by half the overshoot (0.5 % .. 5 %); on time: probe 0.4 % faster.
-    if (pace && p.pace_adapt && K >= 64 && (uint32_t)tile % p.pace_sample == 0u) {
+    // ---- pace control: every tile compares its elapsed time with the schedule.
+    //   on time (<= 1.5 % over)   tile 0 votes for a pace 0.4 % faster (1.6 % while no collapse has
+    //                             been seen: quick descent from the conservative start value)
+    //   slightly late (<= 5 %)    the memory side is at its limit: vote for pace + half the overshoot
+    //   collapse (> 5 %)          the pace was beyond the cliff: vote +3 % and raise the floor to
+    //                             2.5 % above this pace, so that the probing does not walk straight
+    //                             back into it (the floor decays by 0.1 % per launch)
+    // The slowest vote wins (atomicMax into the slot the next launch reads); only late tiles and
+    // tile 0 touch the words, so a healthy launch costs one store.  (A healthy launch has NO late
+    // tile: all of them finish within 1 % of the schedule; a collapse delays whole XCDs, 64+ tiles.)
+    if (pace && p.pace_adapt && K >= 64) {
         unsigned long long now;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
         const unsigned long long elapsed_fp = (now - pace_t0) << 8, planned_fp = (unsigned long long)K * pace;
-        uint32_t next = pace;
-        if (elapsed_fp > planned_fp + (planned_fp >> 6)) {
-            uint32_t inc = (uint32_t)((elapsed_fp - planned_fp) / (2ull * (unsigned long long)K));
-            const uint32_t lo = pace / 200u, hi = pace / 20u;
-            inc = inc < lo ? lo : (inc > hi ? hi : inc);
-            next = pace + inc;
-        } else {
-            next = pace - (pace >> 8);
+        const bool late = elapsed_fp > planned_fp + (planned_fp >> 6);
+        const bool collapse = elapsed_fp > planned_fp + planned_fp / 20u;
+        if ((late || tile == 0) && lane == 0) {
+            uint32_t next;
+            if (collapse) {
+                next = pace + pace / 33u;
+                atomicMax(&p.pace_state[2], pace + pace / 40u);
+            } else if (late) {
+                uint32_t inc = (uint32_t)((elapsed_fp - planned_fp) / (2ull * (unsigned long long)K));
+                const uint32_t lo = pace / 200u;
+                next = pace + (inc < lo ? lo : inc);
+            } else {
+                next = pace - (pace >> (pace_floor ? 8 : 6));   // no collapse seen yet: descend quickly
+            }
+            next = next < p.pace_min_fp ? p.pace_min_fp : (next > p.pace_max_fp ? p.pace_max_fp : next);
+            atomicMax(&p.pace_state[p.pace_slot ^ 1u], next);
         }
-        next = next < p.pace_min_fp ? p.pace_min_fp : (next > p.pace_max_fp ? p.pace_max_fp : next);
-        if (lane == 0) atomicMax(&p.pace_state[p.pace_slot ^ 1u], next);
     }
 
     // ---- registers -> state ------------------------------------------------------------------

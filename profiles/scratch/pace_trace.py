@@ -1,0 +1,27 @@
+"""Trace of the adaptive pace controller: pace read back after every launch and the launch's duration.
+usage: python profiles/scratch/pace_trace.py [workload] [launches]"""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+from bench import workload_config  # noqa: E402
+from collectivecrossing_amd.batched import BatchedCollectiveCrossing  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+cfg, E = workload_config(wl)
+K = 500 if wl == "c2" else 100
+env = BatchedCollectiveCrossing(cfg, E)
+env.set_timing(True)
+env.make_reset_pool(0, 512, on_device=True)
+env.reset_from_pool()
+N = env.num_agents
+acts = torch.randint(0, 5, (K, E, N), dtype=torch.uint8, device=env.device)
+traj = env.alloc_rollout(K)
+print(f"{wl}: start pace {env.step_pace_ns():.0f} ns")
+for i in range(n):
+    env.rollout(acts, auto_reset=True, out=traj)
+    ms = env.last_launch_ms()
+    print(f"launch {i:2d}: {ms * 1000 / K:7.3f} us/env-step   next pace {env.step_pace_ns():7.0f} ns", flush=True)
