@@ -568,14 +568,20 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     unsigned long long pace_t0 = 0, pace_due = 0;   // ticks, ticks x 256 since t0
     if (want_obs && p.pace_state && K >= 16) {   // (short launches: not worth the load)
         // pace_state: [0], [1] = the pace slots (one is read, the other collects this launch's votes),
-        // [2] = floor: the pace just above the last collapse, decaying by 0.1 % per launch
+        // [2] = floor: the pace just above the last collapse; it decays by 0.1 % per launch at first
+        // and twice as fast after every 8 further launches without a collapse ([3] counts them), so
+        // that a transient (the first milliseconds of a process collapse at paces that are fine
+        // later) does not hold the pace up for long while a persistent cliff is approached slowly
         const uint32_t voted = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + p.pace_slot);
         const uint32_t floor_fp = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + 2);
         pace = __builtin_amdgcn_readfirstlane(voted > floor_fp ? voted : floor_fp);
         pace_floor = __builtin_amdgcn_readfirstlane(floor_fp);
         if (p.pace_adapt && K >= 64 && tile == 0 && lane == 0) {
             p.pace_state[p.pace_slot ^ 1u] = 0u;               // the votes of this launch are collected here
-            p.pace_state[2] = floor_fp - (floor_fp >> 10);
+            const uint32_t streak = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + 3);
+            const uint32_t sh = 10u - (streak >= 32u ? 4u : streak >> 3);
+            p.pace_state[2] = floor_fp - (floor_fp >> sh);
+            p.pace_state[3] = streak < 1000u ? streak + 1u : streak;
         }
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pace_t0)::"memory");
     }
@@ -851,7 +857,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     //   slightly late (<= 5 %)    the memory side is at its limit: vote for pace + half the overshoot
     //   collapse (> 5 %)          the pace was beyond the cliff: vote +3 % and raise the floor to
     //                             2.5 % above this pace, so that the probing does not walk straight
-    //                             back into it (the floor decays by 0.1 % per launch)
+    //                             back into it (the floor decays slowly at first, see above)
     // The slowest vote wins (atomicMax into the slot the next launch reads); only late tiles and
     // tile 0 touch the words, so a healthy launch costs one store.  (A healthy launch has NO late
     // tile: all of them finish within 1 % of the schedule; a collapse delays whole XCDs, 64+ tiles.)
@@ -866,6 +872,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             if (collapse) {
                 next = pace + pace / 33u;
                 atomicMax(&p.pace_state[2], pace + pace / 40u);
+                p.pace_state[3] = 0u;
             } else if (late) {
                 uint32_t inc = (uint32_t)((elapsed_fp - planned_fp) / (2ull * (unsigned long long)K));
                 const uint32_t lo = pace / 200u;

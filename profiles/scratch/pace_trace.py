@@ -11,10 +11,13 @@ from collectivecrossing_amd.batched import BatchedCollectiveCrossing  # noqa: E4
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+fixed = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # ns per env-step, -1 = pacing off, 0 = adaptive
 cfg, E = workload_config(wl)
 K = 500 if wl == "c2" else 100
 env = BatchedCollectiveCrossing(cfg, E)
 env.set_timing(True)
+if fixed:
+    env.set_step_pace(fixed)
 env.make_reset_pool(0, 512, on_device=True)
 env.reset_from_pool()
 N = env.num_agents
