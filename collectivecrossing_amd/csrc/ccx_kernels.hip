@@ -885,6 +885,14 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
         }
     }
 
+#ifdef CCX_TILE_TIMES   // diagnostic (profiles/scratch/tile_times.py): elapsed 10-ns ticks of every tile
+    if (pace && ctr && lane == 0) {
+        unsigned long long now;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+        ctr[kCounterTotals + (size_t)tile * kCounterSlot + 6] = now - pace_t0;
+    }
+#endif
+
     // ---- registers -> state ------------------------------------------------------------------
     if (valid) {
         *fx = (int)((ilo >> 16) & 0xFFu);

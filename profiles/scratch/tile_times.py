@@ -11,9 +11,7 @@ import torch  # noqa: E402
 
 from collectivecrossing_amd import _lib  # noqa: E402
 
-import os  # noqa: E402
-
-_lib.LIB_PATH = ROOT / "collectivecrossing_amd" / "csrc" / "_diag" / ("libccx_%s.so" % os.environ.get("CCX_TT", "tt"))
+_lib.LIB_PATH = ROOT / "collectivecrossing_amd" / "csrc" / "_diag" / "libccx_tt.so"
 from bench import c2_config  # noqa: E402
 from collectivecrossing_amd.batched import BatchedCollectiveCrossing, _device_view_i64  # noqa: E402
 
