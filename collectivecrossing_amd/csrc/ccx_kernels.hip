@@ -281,7 +281,18 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     const int tpb = p.waves_per_block;                                  // tiles per block
     const int role = OUT ? wib / tpb : 0;                               // 0 sim, 1.. writers
     const int tile_in_block = OUT ? wib - role * tpb : wib;
-    const int tile = blockIdx.x * tpb + tile_in_block;
+    // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each
+    // with its own L2 and path to memory.  Workgroups of one XCD take ADJACENT tiles, so an XCD
+    // writes one contiguous eighth of every step's output slab instead of every eighth chunk --
+    // the pace at which the output stream collapses moves from ~740 to ~700 ns per env-step on C2
+    // (profiles/scratch/tile_times.py).
+#ifdef CCX_LINEAR_TILES   // diagnostic: the plain blockIdx -> tile mapping
+    const int bid = blockIdx.x;
+#else
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, q8 = nb >> 3, r8 = nb & 7;
+    const int bid = xcd * q8 + (xcd < r8 ? xcd : r8) + (int)(blockIdx.x >> 3);
+#endif
+    const int tile = bid * tpb + tile_in_block;
     const int g = lane >> GLOG;
     const int i = lane & (G - 1);
     const int gbase = g << GLOG;

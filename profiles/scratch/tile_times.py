@@ -11,7 +11,9 @@ import torch  # noqa: E402
 
 from collectivecrossing_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = ROOT / "collectivecrossing_amd" / "csrc" / "_diag" / "libccx_tt.so"
+import os  # noqa: E402
+
+_lib.LIB_PATH = ROOT / "collectivecrossing_amd" / "csrc" / "_diag" / ("libccx_%s.so" % os.environ.get("CCX_TT", "tt"))
 from bench import c2_config  # noqa: E402
 from collectivecrossing_amd.batched import BatchedCollectiveCrossing, _device_view_i64  # noqa: E402
 
@@ -25,7 +27,7 @@ traj = env.alloc_rollout(K)
 p = C.c_void_p()
 for pace in [int(a) for a in sys.argv[1:]] or [780, 760, 740, 720, 700, 680]:
     env.set_step_pace(pace)
-    for rep in range(4):
+    for rep in range(int(os.environ.get("CCX_TT_REPS", "4"))):
         env.rollout(acts, auto_reset=True, out=traj)
         ms = env.last_launch_ms()
         env._lib.ccx_counters_device_ptr(env._h, C.byref(p))
