@@ -231,7 +231,7 @@ void choose_shape(ccx_handle* h) {
     auto to_fp = [](double ns) { double v = ns / 10.0 * 256.0; return (uint32_t)(v < 1.0 ? 1.0 : (v > 4.0e9 ? 4.0e9 : v)); };
     k.pace_state = (h->step_pace_ns == -1) ? nullptr : h->pace_state;
     k.pace_adapt = (h->step_pace_ns == 0) ? 1u : 0u;
-    k._pad = 0;
+    k.resident_blocks = (uint32_t)s.resident_blocks;
     k.pace_min_fp = to_fp(s.step_bytes / 7800.0);
     k.pace_max_fp = to_fp(s.step_bytes / 1100.0);
     h->pace_init_fp = h->step_pace_ns > 0 ? to_fp((double)h->step_pace_ns) : to_fp(s.step_bytes / 6800.0);

@@ -33,7 +33,8 @@ struct KParams {
     // t0 + s * pace on the 100 MHz s_memrealtime clock; pace = *pace_state in ticks x 256 (0 = off)
     uint32_t* pace_state;                // [pace_slot] is read, [pace_slot ^ 1] collects the votes, [2] = floor
     uint32_t pace_min_fp, pace_max_fp;
-    uint32_t pace_slot, _pad;
+    uint32_t pace_slot;
+    uint32_t resident_blocks;            // workgroups the device holds at once (0 = unknown)
     double r_dest, r_door, r_area, r_f, r_nogoal, r_pen;
     long long env_offset;                // global index of env 0 (sharding)
     long long pool_size;                 // reset-pool entries (0 = none)

@@ -575,7 +575,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     if (!policy) fetch_actions(0);
 
     // ---- step pacing: a smooth, absolute schedule for the output stream ----------
-    uint32_t pace = 0, pace_floor = 0;
+    uint32_t pace = 0, pace_base = 0, pace_floor = 0;
     unsigned long long pace_t0 = 0, pace_due = 0;   // ticks, ticks x 256 since t0
     if (want_obs && p.pace_state && K >= 16) {   // (short launches: not worth the load)
         // pace_state: [0], [1] = the pace slots (one is read, the other collects this launch's votes),
@@ -585,8 +585,21 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
         // later) does not hold the pace up for long while a persistent cliff is approached slowly
         const uint32_t voted = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + p.pace_slot);
         const uint32_t floor_fp = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + 2);
-        pace = __builtin_amdgcn_readfirstlane(voted > floor_fp ? voted : floor_fp);
+        pace_base = __builtin_amdgcn_readfirstlane(voted > floor_fp ? voted : floor_fp);
         pace_floor = __builtin_amdgcn_readfirstlane(floor_fp);
+        // The common pace is per workgroup for a FULL device (p.resident_blocks at once).  A grid of
+        // more workgroups runs in rounds; the workgroups of a partial last round share the same
+        // memory among fewer, so their schedule is proportionally faster (else 1024 workgroups on 768
+        // slots would spend their second round at a third of the drain rate).
+        pace = pace_base;
+        if (p.resident_blocks && gridDim.x > p.resident_blocks) {
+            const uint32_t first = (blockIdx.x / p.resident_blocks) * p.resident_blocks;
+            const uint32_t left = gridDim.x - first;
+            if (left < p.resident_blocks) {
+                pace = (uint32_t)(((unsigned long long)pace_base * left) / p.resident_blocks);
+                pace = pace ? pace : 1u;
+            }
+        }
         if (p.pace_adapt && K >= 64 && tile == 0 && lane == 0) {
             p.pace_state[p.pace_slot ^ 1u] = 0u;               // the votes of this launch are collected here
             const uint32_t streak = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + 3);
@@ -879,17 +892,19 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
         const bool late = elapsed_fp > planned_fp + (planned_fp >> 6);
         const bool collapse = elapsed_fp > planned_fp + planned_fp / 20u;
         if ((late || tile == 0) && lane == 0) {
-            uint32_t next;
+            uint32_t next;                                   // a vote is for the COMMON (full-round) pace
             if (collapse) {
-                next = pace + pace / 33u;
-                atomicMax(&p.pace_state[2], pace + pace / 40u);
+                next = pace_base + pace_base / 33u;
+                atomicMax(&p.pace_state[2], pace_base + pace_base / 40u);
                 p.pace_state[3] = 0u;
             } else if (late) {
-                uint32_t inc = (uint32_t)((elapsed_fp - planned_fp) / (2ull * (unsigned long long)K));
-                const uint32_t lo = pace / 200u;
-                next = pace + (inc < lo ? lo : inc);
+                // half the relative overshoot, at least 0.5 %
+                const unsigned long long over = elapsed_fp - planned_fp;
+                uint32_t inc = (uint32_t)(((unsigned long long)pace_base * over) / (2ull * planned_fp));
+                const uint32_t lo = pace_base / 200u;
+                next = pace_base + (inc < lo ? lo : inc);
             } else {
-                next = pace - (pace >> (pace_floor ? 8 : 6));   // no collapse seen yet: descend quickly
+                next = pace_base - (pace_base >> (pace_floor ? 8 : 6));   // no collapse seen yet: descend quickly
             }
             next = next < p.pace_min_fp ? p.pace_min_fp : (next > p.pace_max_fp ? p.pace_max_fp : next);
             atomicMax(&p.pace_state[p.pace_slot ^ 1u], next);
