@@ -115,6 +115,7 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_set_store_throttle": (C.c_int, [_H, C.c_int32]),
     "ccx_set_step_pace": (C.c_int, [_H, C.c_int32]),
     "ccx_get_step_pace": (C.c_int, [_H, C.POINTER(C.c_float)]),
+    "ccx_get_residency": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccx_get_writer_shape": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccx_get_launch_shape": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -310,9 +310,11 @@ class BatchedCollectiveCrossing:
         check(self._lib.ccx_get_launch_shape(self._h, *[C.byref(x) for x in v]))
         w = [C.c_int32() for _ in range(2)]
         check(self._lib.ccx_get_writer_shape(self._h, *[C.byref(x) for x in w]))
+        r = [C.c_int32() for _ in range(2)]
+        check(self._lib.ccx_get_residency(self._h, *[C.byref(x) for x in r]))
         return dict(zip(("lanes_per_wave", "waves_per_block", "group_lanes", "num_blocks",
-                         "writers_per_tile", "store_throttle"),
-                        (int(x.value) for x in v + w)))
+                         "writers_per_tile", "store_throttle", "resident_blocks"),
+                        (int(x.value) for x in v + w + r[:1])))
 
     def use_stream(self, stream: "torch.cuda.Stream | None" = None) -> None:
         """Launch on ``stream`` (default: torch's current stream of the device) from now on."""

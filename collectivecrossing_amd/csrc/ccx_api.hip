@@ -707,6 +707,13 @@ int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {
     return CCX_OK;
 }
 
+int ccx_get_residency(ccx_handle* h, int32_t* resident_workgroups, int32_t* workgroups) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if (resident_workgroups) *resident_workgroups = h->shape.resident_blocks;
+    if (workgroups) *workgroups = h->shape.num_blocks;
+    return CCX_OK;
+}
+
 int ccx_get_launch_shape(ccx_handle* h, int32_t* lanes_per_wave, int32_t* waves_per_block,
                          int32_t* group_lanes, int32_t* num_blocks) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");

@@ -266,6 +266,9 @@ int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight);
  * ccx_get_step_pace returns the pace in effect (synchronises).  Results never depend on it. */
 int ccx_set_step_pace(ccx_handle* h, int32_t ns_per_env_step);
 int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step);
+/* workgroups of a rollout launch with outputs, and how many of them the device holds at once (a grid
+ * larger than that runs in rounds; the pace of a partial last round is scaled accordingly) */
+int ccx_get_residency(ccx_handle* h, int32_t* resident_workgroups, int32_t* workgroups);
 /* the writers per tile and the store throttle in effect (0 = unlimited) */
 int ccx_get_writer_shape(ccx_handle* h, int32_t* writers_per_tile, int32_t* max_stores_in_flight);
 int ccx_get_launch_shape(ccx_handle* h, int32_t* lanes_per_wave, int32_t* waves_per_block,
