@@ -490,6 +490,12 @@ def test_random_batch_sizes_and_launch_shapes_equal_oracle(oracle, ccx, seed):
                  throttle=int(rng.choice([0, -1, 3, 16, 40])))
 
 
+def test_a_hundred_thousand_envs_equal_the_oracle(oracle, ccx):
+    """A batch far beyond one round of workgroups (100 003 envs: 12 501 tiles, a partial last tile and a
+    partial last round), three auto-reset steps from the end of an episode, shuffled order."""
+    _random_case(oracle, ccx, "g8_rollout_c1", E=100003, K=3, seed=77, shuffle=True, auto_reset=True, p_absent=0.05)
+
+
 def test_full_size_c2_properties(ccx):
     """BASELINE config 2 at full size (4096 x 8): size-independent properties of a long
     auto-reset rollout -- no two active agents ever share a cell, nobody stands in a wall,
