@@ -899,8 +899,9 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                 p.pace_state[3] = 0u;
             } else if (late) {
                 // half the relative overshoot, at least 0.5 %
-                const unsigned long long over = elapsed_fp - planned_fp;
-                uint32_t inc = (uint32_t)(((unsigned long long)pace_base * over) / (2ull * planned_fp));
+                unsigned long long over16 = ((elapsed_fp - planned_fp) << 16) / planned_fp;   // overshoot x 2^16
+                over16 = over16 > 65536ull ? 65536ull : over16;
+                uint32_t inc = (uint32_t)(((unsigned long long)pace_base * over16) >> 17);
                 const uint32_t lo = pace_base / 200u;
                 next = pace_base + (inc < lo ? lo : inc);
             } else {
