@@ -229,7 +229,10 @@ void choose_shape(ccx_handle* h) {
     const double tile_bytes = (double)ew * h->N * (4.0 * (6 + 4 * h->N) + 10.0) + ew;
     s.step_bytes = tile_bytes * tpb * s.resident_blocks;
     auto to_fp = [](double ns) { double v = ns / 10.0 * 256.0; return (uint32_t)(v < 1.0 ? 1.0 : (v > 4.0e9 ? 4.0e9 : v)); };
-    k.pace_state = (h->step_pace_ns == -1) ? nullptr : h->pace_state;
+    // A batch whose resident tiles cannot even fill the drain rate at a fast 0.45 us per env-step is
+    // bound by the step chain, not by memory: pacing could only cost it (a clock read per step).
+    const bool can_saturate = s.step_bytes / 7000.0 >= 450.0;
+    k.pace_state = (h->step_pace_ns == -1 || (h->step_pace_ns == 0 && !can_saturate)) ? nullptr : h->pace_state;
     k.pace_adapt = (h->step_pace_ns == 0) ? 1u : 0u;
     k.resident_blocks = (uint32_t)s.resident_blocks;
     k.pace_min_fp = to_fp(s.step_bytes / 7800.0);
@@ -695,7 +698,7 @@ int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {
     if (!h || !ns_per_env_step) return fail(CCX_EINVAL, "NULL argument");
     CCX_HIP(hipSetDevice(h->device));
     uint32_t fp = h->pace_init_fp;
-    if (h->step_pace_ns == -1) {
+    if (!h->kp.pace_state) {   // off, or adaptive on a batch too small to be memory-bound
         fp = 0;
     } else if (!h->pace_dirty) {
         CCX_HIP(hipStreamSynchronize(h->stream));

@@ -575,7 +575,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     if (!policy) fetch_actions(0);
 
     // ---- step pacing: a smooth, absolute schedule for the output stream ----------
-    uint32_t pace = 0, pace_base = 0, pace_floor = 0;
+    uint32_t pace = 0, pace_base = 0, pace_floor = 0, pace_skip = 0;
     unsigned long long pace_t0 = 0, pace_due = 0;   // ticks, ticks x 256 since t0
     if (want_obs && p.pace_state && K >= 16) {   // (short launches: not worth the load)
         // pace_state: [0], [1] = the pace slots (one is read, the other collects this launch's votes),
@@ -636,11 +636,19 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             if (pace) {   // env-step s is due at t0 + s * pace; a late tile does not wait (it catches up)
                 const unsigned long long due = pace_t0 + (pace_due >> 8);
                 pace_due += pace;
-                while (true) {
+                if (pace_skip) {
+                    --pace_skip;             // clearly behind schedule a moment ago: do not even look
+                } else {
                     unsigned long long now;
                     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-                    if ((long long)(due - now) <= 0) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    // reading the clock stalls the step chain (scalar-memory round trip): a tile that is
+                    // more than half a step behind (batches too small to be memory-bound, or a collapse)
+                    // checks again only three steps later
+                    if ((long long)(now - due) > (long long)(pace >> 9)) pace_skip = 3;
+                    while ((long long)(due - now) > 0) {
+                        __builtin_amdgcn_s_sleep(1);
+                        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+                    }
                 }
             }
             if (d == 8) acur = apk[1];

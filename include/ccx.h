@@ -261,7 +261,8 @@ int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight);
  * t0 + s * pace on the GPU's 100 MHz clock, which turns the output into a smooth stream at (just under)
  * the HBM drain rate instead of bursts that oversubscribe the write queues.
  *   0  = adaptive (default): starts from an assumed 6.8 TB/s and is retuned by the kernel after every
- *        launch of >= 64 steps (late => slower, on time => 0.4 % faster)
+ *        launch of >= 64 steps (late => slower, on time => 0.4 % faster); batches too small to fill the
+ *        drain rate are not paced at all
  *   -1 = off;   > 0 = fixed pace in nanoseconds per env-step.
  * ccx_get_step_pace returns the pace in effect (synchronises).  Results never depend on it. */
 int ccx_set_step_pace(ccx_handle* h, int32_t ns_per_env_step);
