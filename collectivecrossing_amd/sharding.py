@@ -44,9 +44,14 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
             # CCX_DIST_BACKEND=gloo lets the N>1 path be rehearsed where RCCL cannot run (CPU box,
             # or several ranks sharing one GPU)
             backend = os.environ.get("CCX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # RCCL: bind the rank to its GPU before the communicator exists (barrier / all_reduce then
+            # need no device guessing)
+            dev = local % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(dev)
+            kw["device_id"] = torch.device("cuda", dev)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
