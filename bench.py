@@ -288,6 +288,7 @@ def main() -> int:
             "value": env_sps, "unit": "env-steps/s", "agent_steps_per_sec": env_sps * N,
             "live_agent_steps_per_sec": counters["live_agent_steps"] / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "collective_backend": (torch.distributed.get_backend() if world > 1 else None),
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "dtypes": "int32/u8 state and flags, f32 observations (exact integers), f64 rewards (one multiply)",

@@ -51,7 +51,18 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
             dev = local % max(1, torch.cuda.device_count())
             torch.cuda.set_device(dev)
             kw["device_id"] = torch.device("cuda", dev)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        except Exception as exc:   # noqa: BLE001
+            # The data path needs no collective; only 48 bytes of counters and the timing barrier do.
+            # If RCCL cannot come up on this node, run them over gloo rather than lose the run
+            # (every rank takes the same branch: the rendezvous failed for all of them).
+            if backend != "nccl":
+                raise
+            print(f"[sharding] nccl init failed ({exc!r}); using gloo for the counter all-reduce", flush=True)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     return rank, world, local
 
 
