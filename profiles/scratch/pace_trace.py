@@ -6,6 +6,11 @@ from pathlib import Path
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import os  # noqa: E402
+
+if os.environ.get("CCX_DIAG_LIB"):   # an experimental build (make variant NAME=...)
+    from collectivecrossing_amd import _abi, _lib
+    _lib.LIB_PATH = Path(os.environ["CCX_DIAG_LIB"]).resolve()
 from bench import workload_config  # noqa: E402
 from collectivecrossing_amd.batched import BatchedCollectiveCrossing  # noqa: E402
 
