@@ -490,6 +490,36 @@ def test_random_batch_sizes_and_launch_shapes_equal_oracle(oracle, ccx, seed):
                  throttle=int(rng.choice([0, -1, 3, 16, 40])))
 
 
+def test_consecutive_long_launches_with_the_adaptive_pace_equal_the_oracle(oracle, ccx):
+    """Five launches of 160 steps in a row (the pace controller votes after each and the next launch
+    reads the vote), 4096 envs so that the batch is paced at all: every launch bit-exact vs the oracle."""
+    from collectivecrossing_amd.reset import build_reset_pool
+
+    g = Golden("g8_rollout_c1")
+    E, K = 4096, 160
+    rng = np.random.default_rng(5)
+    ob = oracle.OracleBatch(g.params, E)
+    env = ccx(g.config, E)
+    pool = build_reset_pool(g.config, 900, 300)
+    for b in (ob, env):
+        b.set_reset_pool(pool)
+        b.reset_from_pool()
+    paces = [env.step_pace_ns()]
+    for launch in range(5):
+        actions = rng.integers(0, 5, size=(K, E, g.N), dtype=np.uint8)
+        o_obs, o_rew, o_af, o_ef = ob.rollout(actions, None, auto_reset=True)
+        res = env.rollout(actions, auto_reset=True)
+        np.testing.assert_array_equal(_np(res.agent_flags), o_af, err_msg=f"launch {launch}")
+        np.testing.assert_array_equal(_np(res.env_flags), o_ef, err_msg=f"launch {launch}")
+        np.testing.assert_array_equal(_np(res.obs).view(np.uint32), o_obs.view(np.uint32), err_msg=f"launch {launch}")
+        np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64), err_msg=f"launch {launch}")
+        paces.append(env.step_pace_ns())
+        del res
+    assert paces[0] > 0 and len(set(paces)) > 1, paces      # the controller did retune
+    assert env.counters() == ob.counters.as_dict()
+    env.close()
+
+
 def test_a_hundred_thousand_envs_equal_the_oracle(oracle, ccx):
     """A batch far beyond one round of workgroups (100 003 envs: 12 501 tiles, a partial last tile and a
     partial last round), three auto-reset steps from the end of an episode, shuffled order."""
