@@ -373,13 +373,22 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                     ? (uint32_t)(reinterpret_cast<uintptr_t>(obs_s) & 127u) / vbytes : 0u);
             obs_s -= lead * vbytes;                       // line-aligned base; unit q lives at (q + lead)
             const int n4l = n4 + (int)lead;               // one past the last slot of the shifted layout
+            // my store iterations: it0, it0 + it_step, ... below it_end (one iteration = 64 vector units)
+            const int total_its = (n4l + 63) >> 6;
+#ifdef CCX_INTERLEAVED_WRITERS   // diagnostic: writer w takes iterations w, w + nw, ... (1-KiB chunks)
+            const int it0 = w, it_step = nw, it_end = total_its;
+#else   // each writer takes one contiguous share of the region (+0.5 % on C3 / C5 under pacing)
+            const int per_w = (total_its + nw - 1) / nw;
+            const int it0 = w * per_w, it_step = 1;
+            const int it_end = (it0 + per_w) < total_its ? (it0 + per_w) : total_its;
+#endif
             // LDS source addresses of this lane's first kFastObsIters observation stores
             uint32_t oa0[kFastObsIters], oa1[kFastObsIters];
 #pragma unroll
             for (int j = 0; j < kFastObsIters; ++j) {
-                const uint32_t q = (uint32_t)(lane + 64 * (w + nw * j)) - lead;   // wraps below the region
+                const uint32_t q = (uint32_t)(lane + 64 * (it0 + it_step * j)) - lead;   // wraps below the region
                 oa0[j] = oa1[j] = kCstOff + 16u;
-                if (want_obs && q < (uint32_t)n4) {
+                if (want_obs && (it0 + it_step * j) < it_end && q < (uint32_t)n4) {
                     if constexpr (PAIR) {
                         const uint32_t t = reinterpret_cast<const uint32_t*>(table)[q];
                         oa0[j] = t & 0xFFFFu;
@@ -389,8 +398,8 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                     }
                 }
             }
-            const uint32_t q0_off = (uint32_t)(lane + 64 * w) * vbytes;   // byte offset of iteration 0
-            const uint32_t it_stride = 64u * (uint32_t)nw * vbytes;       // between my iterations
+            const uint32_t q0_off = (uint32_t)(lane + 64 * it0) * vbytes;       // byte offset of my first iteration
+            const uint32_t it_stride = 64u * (uint32_t)it_step * vbytes;        // between my iterations
             const char* sbase = reinterpret_cast<const char*>(wl);
             CCX_STAMP_DECL;
 
@@ -432,7 +441,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                     // wave pays one LDS latency per batch, then the stores
 #pragma unroll
                     for (int j0 = 0; j0 < kFastObsIters; j0 += kObsBatch) {
-                        if (64 * (w + nw * j0) < n4l) {
+                        if ((it0 + it_step * j0) < it_end) {
                             float2 va[kObsBatch], vb[kObsBatch];
 #pragma unroll
                             for (int j = 0; j < kObsBatch; ++j) {
@@ -442,8 +451,8 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                             }
 #pragma unroll
                             for (int j = 0; j < kObsBatch; ++j) {
-                                const uint32_t q = (uint32_t)(lane + 64 * (w + nw * (j0 + j))) - lead;
-                                if (q < (uint32_t)n4) {
+                                const uint32_t q = (uint32_t)(lane + 64 * (it0 + it_step * (j0 + j))) - lead;
+                                if ((it0 + it_step * (j0 + j)) < it_end && q < (uint32_t)n4) {
                                     char* dst = obs_s + (q0_off + (uint32_t)(j0 + j) * it_stride);
                                     if constexpr (PAIR) {
                                         v4f v = {va[j].x, va[j].y, vb[j].x, vb[j].y};
@@ -456,7 +465,8 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                         }
                     }
                     // beyond the register-cached iterations: table-driven
-                    for (int ql = lane + 64 * (w + nw * kFastObsIters); ql < n4l; ql += 64 * nw) {
+                    for (int it = it0 + it_step * kFastObsIters; it < it_end; it += it_step) {
+                        const int ql = lane + 64 * it;
                         const uint32_t q = (uint32_t)ql - lead;
                         if (q >= (uint32_t)n4) continue;
                         if constexpr (PAIR) {
