@@ -45,23 +45,34 @@ def sample_initial_positions(config, rng: np.random.Generator) -> np.ndarray:
     taken: set[tuple[int, int]] = set()
     out = []
     for _ in range(config.num_boarding_agents):
-        while True:
+        for _draw in range(_MAX_DRAWS):
             x = int(rng.integers(0, W))
             y = int(rng.integers(0, div))
             if (_cell_ok(x, y, W, H, div, tl, tr, dl, dr) and (x, y) not in taken
                     and not (dl <= x <= dr and y == div - 1)):
                 break
+        else:
+            raise RuntimeError(_NO_ROOM.format("boarding"))
         taken.add((x, y))
         out.append((x, y))
     for _ in range(config.num_exiting_agents):
-        while True:
+        for _draw in range(_MAX_DRAWS):
             x = int(rng.integers(tl, tr + 1))
             y = int(rng.integers(div, H))
             if _cell_ok(x, y, W, H, div, tl, tr, dl, dr) and (x, y) not in taken:
                 break
+        else:
+            raise RuntimeError(_NO_ROOM.format("exiting"))
         taken.add((x, y))
         out.append((x, y))
     return np.asarray(out, np.int32).reshape(-1, 2)
+
+
+# The reference's rejection loop (collectivecrossing.py:100-150) never gives up: a config without a free
+# legal cell spins forever.  Same draws here, but a placement that needs more than 2^16 draws for one
+# agent -- the bound of the device kernel (ccx_reset.hip) -- is reported instead.
+_MAX_DRAWS = 1 << 16
+_NO_ROOM = "no free legal cell for a(n) {} agent after 65536 draws: the config leaves no room (the reference would loop forever)"
 
 
 def seeded_positions(config, seeds) -> np.ndarray:

@@ -490,6 +490,46 @@ def test_random_batch_sizes_and_launch_shapes_equal_oracle(oracle, ccx, seed):
                  throttle=int(rng.choice([0, -1, 3, 16, 40])))
 
 
+def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
+    """Hypothesis over the config space (the generator of tests/test_oracle_properties.py, plus up to
+    40 agents): grids, door widths, agent mixes, every strategy -- kernel vs oracle, bit-exact, with
+    shuffled move order, omitted agents and auto-reset."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+    from test_oracle_properties import configs
+
+    from collectivecrossing_amd.params import lower_config
+    from collectivecrossing_amd.reset import build_reset_pool
+
+    @settings(max_examples=50, deadline=None, derandomize=True,
+              suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much, HealthCheck.function_scoped_fixture])
+    @given(cfg=configs(), seed=st.integers(0, 2**20), E=st.sampled_from([1, 5, 64, 130, 257]), K=st.integers(1, 48))
+    def run(cfg, seed, E, K):
+        p = lower_config(cfg)
+        N = p.num_boarding + p.num_exiting
+        rng = np.random.default_rng(seed)
+        actions = rng.integers(0, 5, size=(K, E, N), dtype=np.uint8)
+        actions[rng.random((K, E, N)) < 0.05] = 255
+        order = np.argsort(rng.random((K, E, N)), axis=-1).astype(np.uint8) if seed & 1 else None
+        pool = build_reset_pool(cfg, seed % 977, 37)
+        ob, env = oracle.OracleBatch(p, E), ccx(cfg, E)
+        try:
+            for b in (ob, env):
+                b.set_reset_pool(pool)
+                b.reset_from_pool()
+            o_obs, o_rew, o_af, o_ef = ob.rollout(actions, order, auto_reset=True)
+            res = env.rollout(actions, order, auto_reset=True)
+            np.testing.assert_array_equal(_np(res.agent_flags), o_af)
+            np.testing.assert_array_equal(_np(res.env_flags), o_ef)
+            np.testing.assert_array_equal(_np(res.obs).view(np.uint32), o_obs.view(np.uint32))
+            np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64))
+            assert env.counters() == ob.counters.as_dict()
+        finally:
+            env.close()
+
+    run()
+
+
 def test_consecutive_long_launches_with_the_adaptive_pace_equal_the_oracle(oracle, ccx):
     """Five launches of 160 steps in a row (the pace controller votes after each and the next launch
     reads the vote), 4096 envs so that the batch is paced at all: every launch bit-exact vs the oracle."""

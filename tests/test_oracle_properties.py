@@ -19,9 +19,16 @@ def configs(draw):
     Lt = draw(st.integers(4, W))
     dl = draw(st.integers(0, Lt - 2))
     dr = draw(st.integers(dl + 1, Lt))
-    nb, ne = draw(st.integers(0, 5)), draw(st.integers(0, 4))
+    # keep the rejection-sampled reset feasible with room to spare (the reference -- and the restated
+    # host / device samplers -- would spin forever on a config without free cells)
+    tl, tr = W // 2 - Lt // 2, W // 2 + Lt // 2
+    cap_b = W * div - (dr - dl + 1)
+    cap_e = max(0, tr - tl - 1) * max(0, H - div - 1)
+    nb = draw(st.integers(0, max(0, min(5, cap_b // 3))))
+    ne = draw(st.integers(0, max(0, min(4, cap_e // 3))))
     if nb + ne == 0:
-        nb = 1
+        from hypothesis import reject
+        reject()
     reward = draw(st.sampled_from([C.DefaultRewardConfig(), C.SimpleDistanceRewardConfig(distance_penalty_factor=0.3),
                                    C.BinaryRewardConfig(goal_reward=2.0, no_goal_reward=-0.5),
                                    C.ConstantNegativeRewardConfig(step_penalty=-0.25)]))
@@ -37,7 +44,7 @@ def configs(draw):
         reject()
 
 
-@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much])
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much])
 @given(cfg=configs(), seed=st.integers(0, 2**31 - 1))
 def test_step_invariants(oracle, cfg, seed):
     p = lower_config(cfg)
