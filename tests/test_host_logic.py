@@ -181,3 +181,21 @@ def test_shard_ranges_cover_the_batch():
     assert shard_range(32768, 8, 3) == (3 * 4096, 4096)
     with pytest.raises(ValueError):
         shard_range(8, 2, 2)
+
+
+def test_host_placement_gives_up_where_the_reference_would_spin():
+    """The only row of this tram is the division row and its door is sealed -- no legal cell for an exiting agent: the reference's
+    rejection loop never returns (collectivecrossing.py:127-150); ours reports it after 2^16 draws."""
+    import pytest as _pytest
+
+    from collectivecrossing_amd import configs as C
+    from collectivecrossing_amd.reset import make_generator, sample_initial_positions
+
+    cfg = C.CollectiveCrossingConfig.model_construct(
+        width=8, height=4, division_y=3, tram_door_left=1, tram_door_right=2, tram_length=2,
+        num_boarding_agents=1, num_exiting_agents=1, exiting_destination_area_y=0, boarding_destination_area_y=4,
+        reward_config=C.DefaultRewardConfig(), terminated_config=C.IndividualAtDestinationTerminatedConfig(),
+        truncated_config=C.MaxStepsTruncatedConfig(max_steps=10), observation_config=C.DefaultObservationConfig(),
+        render_mode=None)
+    with _pytest.raises(RuntimeError, match="no free legal cell"):
+        sample_initial_positions(cfg, make_generator(0))
