@@ -507,7 +507,8 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
 
     @settings(max_examples=soak or 50, deadline=None, derandomize=not soak,
               suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much, HealthCheck.function_scoped_fixture])
-    @given(cfg=configs(), seed=st.integers(0, 2**20), E=st.sampled_from([1, 5, 64, 130, 257]), K=st.integers(1, 48),
+    @given(cfg=st.one_of(configs(), configs(max_boarding=25, max_exiting=25)), seed=st.integers(0, 2**20),
+           E=st.sampled_from([1, 5, 64, 130, 257]), K=st.integers(1, 48),
            mode=st.sampled_from(["actions", "actions", "greedy", "waiting"]))
     def run(cfg, seed, E, K, mode):
         p = lower_config(cfg)

@@ -13,7 +13,7 @@ from collectivecrossing_amd.reset import seeded_positions
 
 
 @st.composite
-def configs(draw):
+def configs(draw, max_boarding=5, max_exiting=4):
     W, H = draw(st.integers(6, 24)), draw(st.integers(5, 16))
     div = draw(st.integers(2, H - 2))
     Lt = draw(st.integers(4, W))
@@ -24,8 +24,8 @@ def configs(draw):
     tl, tr = W // 2 - Lt // 2, W // 2 + Lt // 2
     cap_b = W * div - (dr - dl + 1)
     cap_e = max(0, tr - tl - 1) * max(0, H - div - 1)
-    nb = draw(st.integers(0, max(0, min(5, cap_b // 3))))
-    ne = draw(st.integers(0, max(0, min(4, cap_e // 3))))
+    nb = draw(st.integers(0, max(0, min(max_boarding, cap_b // 3))))
+    ne = draw(st.integers(0, max(0, min(max_exiting, cap_e // 3))))
     if nb + ne == 0:
         from hypothesis import reject
         reject()
