@@ -100,3 +100,43 @@ def test_random_config_reference_policy_vs_oracle(reference, oracle, index, poli
         np.testing.assert_array_equal(mine, want, err_msg=f"{policy} step {s} cfg {cfg}")
         rec.step(s, 0, acts)
         b.step(rec.a["actions"][s], rec.a["order"][s], want_obs=False)
+
+
+@pytest.mark.parametrize("index,policy,eps", [(0, "greedy", 0.3), (1, "waiting", 0.2), (2, "greedy", 0.6),
+                                              (3, "waiting", 0.5), (4, "greedy", 0.1), (5, "waiting", 0.9)])
+def test_host_policy_classes_vs_reference_policies_with_epsilon(reference, index, policy, eps):
+    """collectivecrossing_amd.baseline_policies next to the reference's classes, both seeded with 42, on
+    the same live reference env (mirrored into a host view each step): same action every call."""
+    from _fixtures import config_from_dict
+    from baseline_policies import GreedyPolicy, WaitingPolicy
+
+    from collectivecrossing_amd import baseline_policies as bp
+    from collectivecrossing_amd.env import CollectiveCrossingEnv
+
+    cfg = dict(G.cfg_fuzz(BASE % 100000 + 900 + index),
+               truncated_config=dict(truncated_function="max_steps", max_steps=50))
+    from collectivecrossing import CollectiveCrossingEnv as RefEnv
+
+    ref_env = RefEnv(config=G.build_ref_config(cfg))
+    ref_env.reset(seed=BASE + index)
+    ours = CollectiveCrossingEnv.host_view(config_from_dict(cfg))
+    ref_pol = (GreedyPolicy if policy == "greedy" else WaitingPolicy)(randomness_factor=eps, seed=42)
+    our_pol = (bp.GreedyPolicy if policy == "greedy" else bp.WaitingPolicy)(randomness_factor=eps, seed=42)
+    ids = G.ids_of(cfg)
+    for s in range(45):
+        m = ours._mirror
+        for i, a in enumerate(ids):
+            ag = ref_env._agents[a]
+            m.x[i], m.y[i] = int(ag.position[0]), int(ag.position[1])
+            m.active[i], m.terminated[i], m.truncated[i] = ag.active, ag.terminated, ag.truncated
+        m.touch()
+        assert ours.agents == list(ref_env.agents)
+        acts = {}
+        for a in ref_env.agents:
+            want = int(ref_pol.get_action(a, None, ref_env))
+            got = int(our_pol.get_action(a, None, ours))
+            assert got == want, f"{policy} eps {eps} step {s} agent {a} cfg {cfg}"
+            acts[a] = want
+        _, _, term, trunc, _ = ref_env.step(acts)
+        if term["__all__"] or trunc["__all__"]:
+            break
