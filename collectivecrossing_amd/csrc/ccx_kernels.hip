@@ -266,6 +266,14 @@ constexpr int kObsBatch = 5;       // LDS reads issued back to back before their
 //        OCC = false: all-pairs compare through the xch tile (grids whose tables exceed LDS).
 // wave index in block -> role = wib / tiles_per_block (0 = sim, 1.. = writer), tile = wib % tpb.
 // ---------------------------------------------------------------------------------------------
+#ifdef CCX_TSTAMPS   // diagnostic (profiles/scratch/tstamps.py): raw s_memtime at fixed points of tile 0's sim wave
+#define CCX_T(q) do { if (counters && blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_; \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    counters[8 + (q)] = t_; } } while (0)
+#else
+#define CCX_T(q) do { } while (0)
+#endif
+
 template <int GLOG, bool PAIR, bool OUT, bool OCC>
 __global__ void __launch_bounds__(512)
 rollout_kernel(const KParams p, const KState st, const unsigned long long* __restrict__ cell_info,
@@ -276,6 +284,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     constexpr int G = 1 << GLOG;
     extern __shared__ __align__(16) unsigned char smem[];
 
+    CCX_T(0);
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
     const int tpb = p.waves_per_block;                                  // tiles per block
@@ -326,7 +335,9 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             reinterpret_cast<uint32_t*>(smem + p.off_tiles + ti * p.tile_stride + p.off_occ)[w] = 0u;
         }
     }
+    CCX_T(1);
     __syncthreads();  // tables are read-only / zeroed from here on
+    CCX_T(2);
 
     int envs_here = p.E - env0;
     envs_here = envs_here < 0 ? 0 : (envs_here > p.EW ? p.EW : envs_here);
@@ -583,6 +594,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
         act_p += (size_t)kActBatch * EN_v;
     };
     if (!policy) fetch_actions(0);
+    CCX_T(3);
 
     // ---- step pacing: a smooth, absolute schedule for the output stream ----------
     uint32_t pace = 0, pace_base = 0, pace_floor = 0, pace_skip = 0;
@@ -892,6 +904,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
         }
     }
     CCX_STAMP_FLUSH(ctr, 0);
+    CCX_T(4);
 
     // ---- pace control: every tile compares its elapsed time with the schedule.
     //   on time (<= 1.5 % over)   tile 0 votes for a pace 0.4 % faster (1.6 % while no collapse has
@@ -938,6 +951,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     }
 #endif
 
+    CCX_T(5);
     // ---- registers -> state ------------------------------------------------------------------
     if (valid) {
         *fx = (int)((ilo >> 16) & 0xFFu);
@@ -967,6 +981,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             atomicAdd(&slot[5], (unsigned long long)arrivals);
         }
     }
+    CCX_T(6);
 }
 
 // totals[q] = sum over the per-tile partial slots (q = 0..5); one workgroup

@@ -22,7 +22,7 @@ env.reset_from_pool()
 acts = torch.randint(0, 5, (64, E, N), dtype=torch.uint8, device=env.device)
 p = C.c_void_p()
 env._lib.ccx_counters_device_ptr(env._h, C.byref(p))
-names = ["entry->tables built", "syncthreads", "state/pool/action loads issued", "step loop", "(flush)", "state stores + counters"]
+names = ["entry->tables built", "syncthreads", "state/pool/action loads issued", "step loop", "pace vote", "state stores + counters"]
 for K in (1, 1, 1, 16, 64):
     env.rollout(acts[:K], auto_reset=True)
     env.synchronize()
