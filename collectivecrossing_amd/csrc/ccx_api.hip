@@ -18,6 +18,9 @@
 
 namespace {
 
+// a tile's observation region has at most 64 lanes x (3 + 2 * 64) float2 units (+ pad)
+constexpr size_t kMaxObsUnits = 64u * (3u + 2u * 64u) + 2u;
+
 thread_local char g_err[512] = "";
 
 int fail(int code, const char* fmt, ...) {
@@ -65,6 +68,8 @@ struct ccx_handle {
     uint32_t* pace_state = nullptr;                            // device: current pace (ticks x 256)
     uint32_t pace_init_fp = 0;                                 // value to (re)start the controller from
     bool pace_dirty = true;                                    // pace_state must be rewritten before a launch
+    uint16_t* obs_table = nullptr;                             // device: obs address table of the current shape
+    std::vector<uint16_t> obs_table_host;
     uint32_t pace_slot = 0;                                    // slot of pace_state the next launch reads
     int num_cus = 256;
     ccx::LaunchShape shape{};
@@ -235,6 +240,16 @@ void choose_shape(ccx_handle* h) {
     k.pace_state = (h->step_pace_ns == -1 || (h->step_pace_ns == 0 && !can_saturate)) ? nullptr : h->pace_state;
     k.pace_adapt = (h->step_pace_ns == 0) ? 1u : 0u;
     k.resident_blocks = (uint32_t)s.resident_blocks;
+
+    // observation address table of this shape (ccx_kernels.h: obs_unit_addr).  Shape changes are rare and
+    // never happen inside a graph capture: wait for launches that still read the old table, then copy.
+    h->obs_table_host.assign((size_t)units + 2u, 0);
+    for (int w = 0; w < units; ++w) h->obs_table_host[(size_t)w] = ccx::obs_unit_addr((uint32_t)w, h->N, glog);
+    (void)hipStreamSynchronize(h->stream);
+    if (hipMemcpy(h->obs_table, h->obs_table_host.data(), h->obs_table_host.size() * sizeof(uint16_t),
+                  hipMemcpyHostToDevice) != hipSuccess)
+        (void)hipGetLastError();   // surfaces as a wrong-result test failure rather than silently: see ccx_create
+    k.obs_table = h->obs_table;
     k.pace_min_fp = to_fp(s.step_bytes / 7800.0);
     k.pace_max_fp = to_fp(s.step_bytes / 1100.0);
     h->pace_init_fp = h->step_pace_ns > 0 ? to_fp((double)h->step_pace_ns) : to_fp(s.step_bytes / 6800.0);
@@ -369,6 +384,7 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     alloc((void**)&h->counters, ccx::counter_words(h->E) * sizeof(unsigned long long));
     alloc((void**)&h->placement_scratch, en * 2);
     alloc((void**)&h->pace_state, 4 * sizeof(uint32_t));
+    alloc((void**)&h->obs_table, kMaxObsUnits * sizeof(uint16_t));
     if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess ||
         h->num_cus < 1)
         h->num_cus = 256;
@@ -412,6 +428,7 @@ void ccx_destroy(ccx_handle* h) {
     (void)hipFree(h->st.episode);
     (void)hipFree(h->counters);
     (void)hipFree(h->pace_state);
+    (void)hipFree(h->obs_table);
     (void)hipFree(h->cell_info);
     (void)hipFree(h->placement_scratch);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);

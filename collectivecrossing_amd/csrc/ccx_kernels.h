@@ -35,6 +35,9 @@ struct KParams {
     uint32_t pace_min_fp, pace_max_fp;
     uint32_t pace_slot;
     uint32_t resident_blocks;            // workgroups the device holds at once (0 = unknown)
+    // u16 LDS source address of every float2 unit of a tile's observation region, built on the host
+    // for this (glog, EW, N) and copied to LDS at kernel start (units_per_wave + 1 entries)
+    const uint16_t* obs_table;
     double r_dest, r_door, r_area, r_f, r_nogoal, r_pen;
     long long env_offset;                // global index of env 0 (sharding)
     long long pool_size;                 // reset-pool entries (0 = none)
@@ -57,6 +60,24 @@ struct KOut {
     uint8_t* agent_flags;
     uint8_t* env_flags;
 };
+
+// LDS tile a writer wave gathers observation rows from: float4 (x, y, type, active) per lane, then
+// 8 floats of constants.  obs_unit_addr: byte offset (from that tile) of the 8 bytes that go to float2
+// unit `w` of a tile's observation region.  Row layout (observations.py:64-92): unit 0 = (x_i, y_i);
+// unit 1 = (door_centre, division_y); unit 2 = (door_left, door_right); unit 3+2j = (x_j, y_j),
+// unit 4+2j = (type_j, active_j), or (-1, -1) for j == i.
+constexpr uint32_t kObsCstOff = 1024;
+__host__ __device__ inline uint16_t obs_unit_addr(uint32_t w, int N, int glog) {
+    const uint32_t U = 3u + 2u * (uint32_t)N;
+    const uint32_t row = w / U, u = w - row * U;
+    const uint32_t el = row / (uint32_t)N, i = row - el * (uint32_t)N;
+    const uint32_t gb = el << glog;
+    if (u == 0) return (uint16_t)((gb + i) * 16u);
+    if (u < 3) return (uint16_t)(kObsCstOff + (u - 1u) * 8u);
+    const uint32_t j = (u - 3u) >> 1, hh = (u - 3u) & 1u;
+    if (j == i) return (uint16_t)(kObsCstOff + 16u);
+    return (uint16_t)((gb + j) * 16u + hh * 8u);
+}
 
 // Device counters: [0..5] totals (ccx_counters), [7] failed placements, [8..15] diagnostic builds, then
 // one slot of kCounterSlot words per env tile that the rollout kernel adds to (a tile index never

@@ -153,31 +153,17 @@ struct WSlot {
     float cst[8];      // (door_centre, division_y) (door_left, door_right) (-1,-1) pad
 };
 static_assert(sizeof(WSlot) == 1024 + 32, "WSlot layout");
-static constexpr uint32_t kCstOff = 1024;  // byte offset of cst[] from slot[]
+static constexpr uint32_t kCstOff = kObsCstOff;  // byte offset of cst[] from slot[]
 using WaveLds = WSlot;
 
-// u16 table entry for float2 unit `w` of a tile's observation region: byte offset (from the
-// tile's WaveLds) of the 8 bytes to copy there.  Row layout (observations.py:64-92):
-//   unit 0 = (x_i, y_i); unit 1 = (door_centre, division_y); unit 2 = (door_left, door_right);
-//   unit 3+2j = (x_j, y_j), unit 4+2j = (type_j, active_j), or (-1,-1) for j == i.
-template <int GLOG>
-__device__ __forceinline__ uint16_t obs_unit_addr(uint32_t w, int N, int U) {
-    uint32_t row = w / (uint32_t)U, u = w - row * (uint32_t)U;
-    uint32_t el = row / (uint32_t)N, i = row - el * (uint32_t)N;
-    uint32_t gb = el << GLOG;
-    if (u == 0) return (uint16_t)((gb + i) * 16u);
-    if (u < 3) return (uint16_t)(kCstOff + (u - 1u) * 8u);
-    uint32_t j = (u - 3u) >> 1, h = (u - 3u) & 1u;
-    if (j == i) return (uint16_t)(kCstOff + 16u);
-    return (uint16_t)((gb + j) * 16u + h * 8u);
-}
-
+// The u16 observation address table (ccx_kernels.h: obs_unit_addr) comes from the host, like the cell
+// table: computing it per launch cost ~1 us of integer divisions in every workgroup.
 template <int GLOG>
 __device__ __forceinline__ void build_obs_table(uint16_t* table, const KParams& p) {
-    const int U = 3 + 2 * p.N;
-    for (uint32_t w = threadIdx.x; w < (uint32_t)p.units_per_wave; w += blockDim.x)
-        table[w] = obs_unit_addr<GLOG>(w, p.N, U);
-    if (threadIdx.x == 0 && (p.units_per_wave & 1)) table[p.units_per_wave] = 0;
+    const uint32_t words = ((uint32_t)p.units_per_wave + 2u) >> 1;          // u16 pairs, incl. the pad entry
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.obs_table);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(table);
+    for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
 }
 
 __device__ __forceinline__ void init_wave_consts(WaveLds* wl, const KParams& p, int lane) {
@@ -327,13 +313,35 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     uint4* stage = reinterpret_cast<uint4*>(tbase + 256);
     uint16_t* table = reinterpret_cast<uint16_t*>(smem + p.off_table);
     const bool want_obs = OUT && out.obs != nullptr;
-    for (uint32_t t = threadIdx.x; t < cells; t += blockDim.x) cinfo[t] = cell_info[t];
-    if (want_obs) build_obs_table<GLOG>(table, p);
+    // Prologue: both host-built tables come from global memory (L2-resident after the first
+    // workgroup).  The first chunk of each is requested before anything else so that ONE memory
+    // latency covers both and the LDS zeroing below; small grids (C2: 143 cells, 609 table words)
+    // need nothing more.
+    const uint32_t tw = want_obs ? (((uint32_t)p.units_per_wave + 2u) >> 1) : 0u;   // u16 pairs of the obs table
+    const uint32_t* tsrc = reinterpret_cast<const uint32_t*>(p.obs_table);
+    const unsigned long long c_first = threadIdx.x < cells ? cell_info[threadIdx.x] : 0ull;
+    uint32_t t_first[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const uint32_t w = threadIdx.x + (uint32_t)r * blockDim.x;
+        t_first[r] = w < tw ? tsrc[w] : 0u;
+    }
     if constexpr (OCC) {   // zero the occupancy / proposal tables of every tile of the block
-        for (uint32_t t = threadIdx.x; t < (uint32_t)tpb * p.occ_words; t += blockDim.x) {
-            const uint32_t ti = t / p.occ_words, w = t - ti * p.occ_words;
-            reinterpret_cast<uint32_t*>(smem + p.off_tiles + ti * p.tile_stride + p.off_occ)[w] = 0u;
+        for (int ti = 0; ti < tpb; ++ti) {
+            uint32_t* occ = reinterpret_cast<uint32_t*>(smem + p.off_tiles + (uint32_t)ti * p.tile_stride + p.off_occ);
+            for (uint32_t w = threadIdx.x; w < p.occ_words; w += blockDim.x) occ[w] = 0u;
         }
+    }
+    if (threadIdx.x < cells) cinfo[threadIdx.x] = c_first;
+    for (uint32_t t = threadIdx.x + blockDim.x; t < cells; t += blockDim.x) cinfo[t] = cell_info[t];
+    {
+        uint32_t* tdst = reinterpret_cast<uint32_t*>(table);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const uint32_t w = threadIdx.x + (uint32_t)r * blockDim.x;
+            if (w < tw) tdst[w] = t_first[r];
+        }
+        for (uint32_t w = threadIdx.x + 3u * blockDim.x; w < tw; w += blockDim.x) tdst[w] = tsrc[w];
     }
     CCX_T(1);
     __syncthreads();  // tables are read-only / zeroed from here on
