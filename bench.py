@@ -169,7 +169,7 @@ def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40, help="timed rollout launches (bench steps)")
-    ap.add_argument("--warmup", type=int, default=40, help="untimed rollout launches (clock ramp + pace controller)")
+    ap.add_argument("--warmup", type=int, default=80, help="untimed rollout launches (clock ramp + pace controller)")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the workload's own size")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5_50", "c5_64"])
     ap.add_argument("--chunk", type=int, default=500, help="env-steps fused per rollout launch (= per bench step)")
