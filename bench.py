@@ -9,7 +9,9 @@ synthetic input: one fused ``ccx_rollout`` launch that advances every env of the
 (default 500) env-steps from an action tensor [chunk, E, N] resident in HBM and writes the full
 per-step outputs (observations f32 [E,N,L], rewards f64, flag bytes) of every env-step to a trajectory
 buffer in HBM.  `--steps K` / `--warmup W` count such launches (K = 40: 20000 env-steps of 4096 envs);
-the metric stays env-steps/s = K * chunk * envs / elapsed.
+the metric stays env-steps/s = K * chunk * envs / elapsed.  The first ~30 launches of a process run
+slower (clock ramp, pace controller): W defaults to 80, and a smaller W is topped up by untimed set-up
+launches that the JSON line reports as config.settle_launches.
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
@@ -247,6 +249,11 @@ def main() -> int:
                 e1.record()
                 events.append((e0, e1))
 
+    # The first ~30 launches of a process are slower (clock ramp; the pace controller starts from a
+    # conservative value).  The default --warmup covers that; when the caller asks for
+    # fewer warm-up steps the difference is run first as untimed set-up and reported as such.
+    settle = max(0, 80 - args.warmup) if not os.environ.get("CCX_BENCH_NO_SETTLE") else 0
+    run(settle)
     run(args.warmup)
     env.zero_counters()
     torch.cuda.synchronize(dev)
@@ -303,6 +310,7 @@ def main() -> int:
                        "step": "one fused rollout launch over an action batch [env_steps_per_step, envs, agents]",
                        "env_steps_per_step": chunk, "steps_per_launch": chunk,
                        "ms_per_env_step": elapsed * 1e3 / (args.steps * chunk),
+                       "settle_launches": settle,
                        "launch_shape": env.launch_shape(), "step_pace_ns": env.step_pace_ns(),
                        "outputs": "full trajectory" + (" (no obs)" if args.no_obs else "")},
             "counters": counters,
