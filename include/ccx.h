@@ -261,8 +261,8 @@ int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight);
  * t0 + s * pace on the GPU's 100 MHz clock, which turns the output into a smooth stream at (just under)
  * the HBM drain rate instead of bursts that oversubscribe the write queues.
  *   0  = adaptive (default): starts from an assumed 6.8 TB/s and is retuned by the kernel after every
- *        launch of >= 64 steps (late => slower, on time => 0.4 % faster); batches too small to fill the
- *        drain rate are not paced at all
+ *        launch of >= 64 steps (late => slower, on time => 0.4 % faster, a collapse of the drain rate =>
+ *        +3 % and a decaying floor); batches too small to fill the drain rate are not paced at all
  *   -1 = off;   > 0 = fixed pace in nanoseconds per env-step.
  * ccx_get_step_pace returns the pace in effect (synchronises).  Results never depend on it. */
 int ccx_set_step_pace(ccx_handle* h, int32_t ns_per_env_step);
@@ -275,13 +275,13 @@ int ccx_get_writer_shape(ccx_handle* h, int32_t* writers_per_tile, int32_t* max_
 int ccx_get_launch_shape(ccx_handle* h, int32_t* lanes_per_wave, int32_t* waves_per_block,
                          int32_t* group_lanes, int32_t* num_blocks);
 
-/* rebind the handle to another HIP stream of its device (synchronises the old one first) */
 /* Zero-copy I/O for single-env stepping (the dict API of collectivecrossing.py:161-261 needs every
  * output on the host after each step): the device address of page-locked host memory (hipHostMalloc /
  * hipHostRegister, e.g. a torch pinned tensor).  Pass it to ccx_step as actions / outputs and the
  * kernel reads and writes the host buffer over the host link -- one launch + one sync per step,
  * no memcpy.  Fails with CCX_EINVAL for pageable or unregistered memory. */
 int ccx_host_device_pointer(ccx_handle* h, void* pinned_host, void** device_ptr);
+/* rebind the handle to another HIP stream of its device (synchronises the old one first) */
 int ccx_set_stream(ccx_handle* h, void* stream);
 int ccx_synchronize(ccx_handle* h);
 
