@@ -6,7 +6,7 @@ mkdir -p gpurun_out/ab
 for rep in 1 2; do
   for L in $1; do
     for W in $2; do
-      X="--steps 40 --warmup 40"; [ $W != c2 ] && X="--chunk 100 --steps 24 --warmup 24 --pool 512"
+      X="--steps 40 --warmup 80"; [ $W != c2 ] && X="--chunk 100 --steps 24 --warmup 24 --pool 512"
       CCX_DIAG_LIB=collectivecrossing_amd/csrc/_diag/libccx_$L.so timeout -k 10 90 python bench.py --no-cpu-baseline --workload $W $X > gpurun_out/ab/${L}_${W}_$rep.json 2> gpurun_out/ab/${L}_${W}_$rep.err || { tail -3 gpurun_out/ab/${L}_${W}_$rep.err; exit 1; }
     done
   done
