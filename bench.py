@@ -9,16 +9,26 @@ synthetic input: one fused ``ccx_rollout`` launch that advances every env of the
 (default 500) env-steps from an action tensor [chunk, E, N] resident in HBM and writes the full
 per-step outputs (observations f32 [E,N,L], rewards f64, flag bytes) of every env-step to a trajectory
 buffer in HBM.  `--steps K` / `--warmup W` count such launches (K = 40: 20000 env-steps of 4096 envs);
-the metric stays env-steps/s = K * chunk * envs / elapsed.  The first ~30 launches of a process run
-slower (clock ramp, pace controller): W defaults to 80, and a smaller W is topped up by untimed set-up
-launches that the JSON line reports as config.settle_launches.
+the metric stays env-steps/s = K * chunk * envs / elapsed.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  `value` = env-steps/s over ALL ranks with inputs resident in HBM,
-timed between barrier + synchronize pairs, max over ranks.  Weak scaling: every rank owns 4096
-envs of a global batch of N*4096; envs are independent, the only collective is the 48-byte
-all-reduce of the counters after the timed window.
+N > 1 works both ways: started by ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``
+(WORLD_SIZE is set: this process is one rank) or as the bare command (WORLD_SIZE unset: this process
+only LAUNCHES N rank processes -- before anything touches a GPU -- relays rank 0's JSON line and
+returns the worst exit code).  One rank per GPU over RCCL; RCCL failing to come up is fatal.
+
+Timing protocol.  Exactly W untimed launches, then K timed launches between barrier + synchronize
+pairs, max over ranks: that is the `cold` block of the line.  The first ~30 launches of a process run
+slower (clock ramp, pace controller start-up), so when W + K < 80 the difference is
+run as further untimed set-up (`config.settle_launches`) and K launches are timed again the same way:
+`value` is that steady-state figure, `cold.value` the one a caller with exactly W warm-ups sees; with
+W >= 80 they are the same measurement.
+
+Prints ONE JSON line on rank 0.  `value` = env-steps/s over ALL ranks with inputs resident in HBM.
+Weak scaling: every rank owns 4096 envs of a global batch of N*4096; envs are independent, the only
+collective is the 48-byte all-reduce of the device-resident counters after the timed window (plus the
+timing barrier and the max / gather of the per-rank elapsed times).
 """
 
 from __future__ import annotations
@@ -26,6 +36,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -34,10 +46,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+SETTLE_LAUNCHES = 80   # launches after which a process is in steady state
 
 
 def c2_config(max_steps: int = 100):
@@ -84,7 +94,7 @@ def rollout_bytes_per_agent_step(n_agents: int) -> int:
     return 4 * (6 + 4 * n_agents) + 1 + 8 + 1
 
 
-def write_bandwidth_probe(dev, buf: torch.Tensor) -> float:
+def write_bandwidth_probe(torch, dev, buf) -> float:
     """Achievable pure-WRITE bandwidth of THIS process in GB/s: best of 7 device fills of the very
     buffer the rollout writes its observations to (the sustained write rate varies by 20-30 %
     between boxes and allocations; SURVEY 8d asks for a measured denominator next to the peak)."""
@@ -104,6 +114,8 @@ def write_bandwidth_probe(dev, buf: torch.Tensor) -> float:
 def cpu_baseline(config, n_agents: int, seconds_target: float = 12.0) -> dict:
     """The CPU oracle (a C port of the reference's sequential algorithm) on the host cores, same
     workload (full trajectory outputs), bounded sample."""
+    import numpy as np
+
     from collectivecrossing_amd.params import lower_config
     from collectivecrossing_amd.reset import build_reset_pool
     from oracle import oracle as ref  # cpu_baseline leg only
@@ -167,11 +179,110 @@ def reference_python_speed():
         return None
 
 
-def main() -> int:
+def traffic_from_profiles(workload: str, E: int, N: int, chunk: int):
+    """HBM bytes per launch from the PMC passes of an EARLIER rocprofv3 run of this same command
+    (profiles/collect*.sh; counters cannot be collected inside a plain bench run).  Replayed from the
+    tracked file, never measured here -- hence not `roofline.traffic`."""
+    names = ["r02_c2_traffic.json", "r01_traffic.json"] if workload == "c2" else [f"r02_{workload}_traffic.json"]
+    for name in names:
+        f = ROOT / "profiles" / name
+        try:
+            t = json.loads(f.read_text())
+        except Exception:
+            continue
+        if t.get("envs") == E and t.get("chunk") == chunk and t.get("agents") == N:
+            return {"hbm_bytes_per_launch": t.get("hbm_bytes_per_launch"), "file": f"profiles/{name}",
+                    "ratio_to_algorithmic": (t["hbm_bytes_per_launch"] / t["algorithmic_bytes_per_launch"]
+                                             if t.get("algorithmic_bytes_per_launch") else None)}
+    return None
+
+
+# --------------------------------------------------------------------------------------------------
+# N > 1 from the bare command: this process becomes a launcher and never touches a GPU
+# --------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv: list[str]) -> int:
+    """Start n fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, like torch.distributed.run does), relay rank 0's stdout, return the worst exit code.
+    The launcher has imported neither torch nor libccx: a process that has initialised the GPU must
+    never be the one that forks / execs the ranks."""
+    port = _free_port()
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=str(port), CCX_BENCH_LAUNCHER="bench.py")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    relay = threading.Thread(target=lambda: [print(ln, end="", flush=True) for ln in procs[0].stdout], daemon=True)
+    relay.start()
+    deadline = time.time() + float(os.environ.get("CCX_BENCH_LAUNCH_TIMEOUT", "1500"))
+    worst = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is not None:
+                alive.discard(r)
+                if rc != 0:
+                    worst = worst or rc
+        if (worst or time.time() > deadline) and alive:
+            # one rank failed (or the job hangs at a rendezvous): end exactly the processes started here
+            why = f"rank exit code {worst}" if worst else "launcher timeout"
+            print(f"[bench] {why}: stopping ranks {sorted(alive)}", file=sys.stderr)
+            for r in alive:
+                procs[r].terminate()
+            for r in alive:
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            worst = worst or 124
+            break
+        time.sleep(0.05)
+    relay.join(timeout=5)
+    return worst
+
+
+def rehearse(args) -> int:
+    """`--rehearse`: the N>1 plumbing WITHOUT any env stepping (no GPU, no libccx needed): rendezvous,
+    barriers, the three collectives of the bench with known per-rank values, one JSON line marked as a
+    rehearsal.  This is what the CPU test-suite runs through the launcher with gloo."""
+    from collectivecrossing_amd import sharding
+    from collectivecrossing_amd._abi import COUNTER_FIELDS
+
+    rank, world, _ = sharding.init_from_env()
+    if world != args.gpus:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+        return 2
+    sharding.barrier()
+    t0 = time.perf_counter()
+    sharding.barrier()
+    elapsed = sharding.allreduce_max(time.perf_counter() - t0 + rank)     # rank r reports r + epsilon
+    counters = sharding.allreduce_counters({k: (rank + 1) * (q + 1) for q, k in enumerate(COUNTER_FIELDS)})
+    per_rank = sharding.allgather_float(float(rank))
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal of the N>1 plumbing (no env was stepped)", "rehearsal": True,
+                          "value": None, "n_gpus": world, "elapsed_max": elapsed, "counters": counters,
+                          "per_rank": per_rank, "launcher": os.environ.get("CCX_BENCH_LAUNCHER", "torch.distributed.run"),
+                          **sharding.group_info()}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return 0
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40, help="timed rollout launches (bench steps)")
-    ap.add_argument("--warmup", type=int, default=80, help="untimed rollout launches (clock ramp + pace controller)")
+    ap.add_argument("--warmup", type=int, default=80, help="untimed rollout launches before the timed ones")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the workload's own size")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5_50", "c5_64"])
     ap.add_argument("--chunk", type=int, default=500, help="env-steps fused per rollout launch (= per bench step)")
@@ -185,9 +296,54 @@ def main() -> int:
                     help="random = actions from a device tensor (the bench line); greedy = the "
                          "reference's GreedyPolicy(epsilon=0) evaluated inside the rollout kernel (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the no-obs / K=1 secondary figures")
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip the observation output")
     ap.add_argument("--only-obs", action="store_true", help="diagnostic: skip reward / flag outputs")
-    args = ap.parse_args()
+    ap.add_argument("--direct-rccl", action="store_true",
+                    help="reduce the counters with ccx_rccl_allreduce_counters (RCCL through the C-ABI) instead of "
+                         "torch.distributed")
+    ap.add_argument("--rehearse", action="store_true", help="N>1 plumbing only, no env stepping (CPU-runnable)")
+    return ap.parse_args(argv)
+
+
+def secondary_figures(torch, env, actions, chunk: int) -> dict:
+    """Two figures next to the headline (rank 0, N=1): the rollout WITHOUT the observation output
+    (the sim chain + small outputs: what bounds small batches) and the latency of a single-step
+    ccx_step launch (K = 1, full outputs), both from HIP events on the launch stream."""
+    dev = env.device
+    E, N = env.num_envs, env.num_agents
+    out = {}
+    small = env.alloc_rollout(chunk, want_obs=False)
+    for _ in range(3):
+        env.rollout(actions[:chunk], auto_reset=True, out=small)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        env.rollout(actions[:chunk], auto_reset=True, out=small)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    out["no_obs"] = {"env_steps_per_sec": chunk * E / (ms * 1e-3), "us_per_env_step": ms * 1e3 / chunk,
+                     "what": f"ccx_rollout, {chunk} steps per launch, rewards + flag bytes only"}
+    del small
+    for _ in range(20):
+        env.step(actions[0])
+    reps = 200
+    e0.record()
+    for k in range(reps):
+        env.step(actions[k % actions.shape[0]])
+    e1.record()
+    torch.cuda.synchronize(dev)
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    out["step_k1"] = {"us_per_step": us, "env_steps_per_sec": E / (us * 1e-6),
+                      "what": f"{reps} back-to-back ccx_step launches (K = 1, full outputs), eager"}
+    return out
+
+
+def run_rank(args) -> int:
+    import numpy as np
+    import torch
 
     if os.environ.get("CCX_DIAG_LIB"):   # diagnostics only: an experimental build of libccx
         import ctypes
@@ -197,14 +353,16 @@ def main() -> int:
         _abi.PROTOTYPES = {k: v for k, v in _abi.PROTOTYPES.items() if hasattr(probe, k)}
     from collectivecrossing_amd import sharding
     from collectivecrossing_amd.batched import BatchedCollectiveCrossing
-    from collectivecrossing_amd.reset import build_reset_pool
 
     rank, world, local = sharding.init_from_env()
     if world != args.gpus:
-        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: start N>1 with "
-              "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`", file=sys.stderr)
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
         return 2
-    local = local % max(1, torch.cuda.device_count())   # one rank per GPU on a full node
+    if not torch.cuda.is_available():
+        print("[bench] no GPU visible: the hot path has no CPU implementation (use --rehearse for the "
+              "N>1 plumbing on CPU)", file=sys.stderr)
+        return 3
+    local = local % max(1, torch.cuda.device_count())   # several ranks may share a GPU under gloo only
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -249,57 +407,78 @@ def main() -> int:
                 e1.record()
                 events.append((e0, e1))
 
-    # The first ~30 launches of a process are slower (clock ramp; the pace controller starts from a
-    # conservative value).  The default --warmup covers that; when the caller asks for
-    # fewer warm-up steps the difference is run first as untimed set-up and reported as such.
-    settle = max(0, 80 - args.warmup) if not os.environ.get("CCX_BENCH_NO_SETTLE") else 0
-    run(settle)
-    run(args.warmup)
-    env.zero_counters()
-    torch.cuda.synchronize(dev)
-    sharding.barrier()
-    torch.cuda.synchronize(dev)
-    events: list = []
-    t0 = time.perf_counter()
-    run(args.steps, events)
-    torch.cuda.synchronize(dev)
-    sharding.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = sharding.allreduce_max(elapsed)
-    counters = sharding.allreduce_counters(env.counters())   # the one RCCL reduction (48 B)
+    def timed_window():
+        """K launches between barrier + synchronize pairs; (elapsed max over ranks, elapsed of this
+        rank, per-launch kernel ms from HIP events on the launch stream, summed counters)."""
+        env.zero_counters()
+        torch.cuda.synchronize(dev)
+        sharding.barrier()
+        torch.cuda.synchronize(dev)
+        events: list = []
+        t0 = time.perf_counter()
+        run(args.steps, events)
+        torch.cuda.synchronize(dev)
+        mine = time.perf_counter() - t0
+        sharding.barrier()
+        elapsed = sharding.allreduce_max(time.perf_counter() - t0)
+        # the one data reduction of the job: 48 bytes, on the device under RCCL
+        counters = direct.allreduce(env) if direct else sharding.allreduce_counters(env.counters_tensor())
+        return elapsed, mine, [a.elapsed_time(b) for a, b in events], counters
 
-    # kernel time from HIP events recorded on the launch stream, per launch
-    full = [a.elapsed_time(b) for a, b in events]
-    kern_ms = float(np.mean(full)) if full else float("nan")
+    direct = sharding.RcclCounterReducer(env, rank, world) if args.direct_rccl else None
     bytes_unit = rollout_bytes_per_agent_step(N) - (4 * L if args.no_obs else 0)
     launch_bytes = bytes_unit * chunk * E * N
-    achieved = launch_bytes / (kern_ms * 1e-3) / 1e9 if full else float("nan")
-    survey_unit = 16 * N + 54 + 4   # SURVEY 8d contract figure, f64 rewards
-    traffic = None
-    tf = ROOT / "profiles" / "r01_traffic.json"
-    if tf.exists():
-        try:
-            t = json.loads(tf.read_text())
-            if t.get("envs") == E and t.get("chunk") == chunk and t.get("agents") == N:
-                traffic = t.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
 
-    probe = write_bandwidth_probe(dev, traj.obs if traj.obs is not None else traj.reward) if rank == 0 else None
+    def summarize(elapsed, launch_ms):
+        kern_ms = float(np.mean(launch_ms)) if launch_ms else float("nan")
+        achieved = launch_bytes / (kern_ms * 1e-3) / 1e9 if launch_ms else float("nan")
+        return {"value": args.steps * chunk * total / elapsed, "ms_per_step": elapsed * 1e3 / args.steps,
+                "kernel_ms_per_launch": kern_ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                "kernel_ms_max_over_median": (float(np.max(launch_ms) / np.median(launch_ms)) if launch_ms else None)}
+
+    # exactly --warmup untimed launches, then the timed window: what a caller with W warm-ups sees
+    run(args.warmup)
+    elapsed, mine, launch_ms, counters = timed_window()
+    cold = summarize(elapsed, launch_ms)
+    settle = 0
+    if args.warmup + args.steps < SETTLE_LAUNCHES and not os.environ.get("CCX_BENCH_NO_SETTLE"):
+        # not in steady state yet (DESIGN.md 3.6): finish the start-up untimed and measure again
+        settle = SETTLE_LAUNCHES - args.warmup - args.steps
+        run(settle)
+        elapsed, mine, launch_ms, counters = timed_window()
+    steady = summarize(elapsed, launch_ms)
+    per_rank = [args.steps * chunk * E / t for t in sharding.allgather_float(mine)]
+
+    probe = write_bandwidth_probe(torch, dev, traj.obs if traj.obs is not None else traj.reward) if rank == 0 else None
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary and args.policy == "random" and not args.no_obs:
+        secondary = secondary_figures(torch, env, actions, chunk)
     if rank == 0:
         assert os.environ.get("CCX_DIAG_LIB") or counters["env_steps"] == args.steps * chunk * total, counters
         props = torch.cuda.get_device_properties(dev)
-        env_sps = args.steps * chunk * total / elapsed
+        env_sps = steady["value"]
+        kern_ms = steady["kernel_ms_per_launch"]
+        survey_unit = 16 * N + 54 + 4   # SURVEY 8d contract figure, f64 rewards
         line = {
             "metric": f"env-steps/sec, random-action rollout, {E} envs x {N} agents per GPU",
             "value": env_sps, "unit": "env-steps/s", "agent_steps_per_sec": env_sps * N,
             "live_agent_steps_per_sec": counters["live_agent_steps"] / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "collective_backend": (torch.distributed.get_backend() if world > 1 else None),
-            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            **sharding.group_info(),
+            "counters_allreduce": (f"ccx_rccl_allreduce_counters ({direct.num_ranks} RCCL rank(s))" if direct
+                                   else "torch.distributed" if world > 1 else None),
+            "launcher": os.environ.get("CCX_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else None),
+            "per_rank_env_steps_per_sec": per_rank,
+            "ms_per_step": steady["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "dtypes": "int32/u8 state and flags, f32 observations (exact integers), f64 rewards (one multiply)",
             "data": "synthetic",
+            "cold": {"what": f"the {args.steps} launches right after exactly {args.warmup} warm-up launches "
+                             "(same barrier + synchronize protocol); `value` is the steady state after "
+                             "config.settle_launches further untimed launches",
+                     "value": cold["value"], "ms_per_step": cold["ms_per_step"],
+                     "kernel_ms_per_launch": cold["kernel_ms_per_launch"],
+                     "ratio_to_value": cold["value"] / env_sps},
             "config": {"workload": ("C2: 4096 envs x (5 boarding + 3 exiting) per GPU, 12x8 grid, "
                                     "DefaultReward + DefaultObservation, individual_at_destination, "
                                     "max_steps=100, uniform random actions, auto-reset from "
@@ -316,25 +495,41 @@ def main() -> int:
             "counters": counters,
             "device": {"name": props.name, "compute_units": props.multi_processor_count,
                        "hbm_GiB": round(props.total_memory / 2**30, 1)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"bound": "hbm", "achieved": steady["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": steady["frac"], "frac_cold": cold["frac"],
+                         "traffic": None,
+                         "traffic_from_profiles": traffic_from_profiles(args.workload, E, N, chunk),
                          "kernel": "ccx::rollout_kernel", "kernel_ms_per_launch": kern_ms,
+                         "kernel_ms_max_over_median": steady["kernel_ms_max_over_median"],
                          "bytes_per_agent_step": bytes_unit, "bytes_per_launch": launch_bytes,
                          "achievable_write_GBs_this_box": probe,
-                         "frac_of_achievable": achieved / probe if probe else None,
-                         "achieved_survey_8d_GBs": (survey_unit * chunk * E * N / (kern_ms * 1e-3) / 1e9
-                                                    if full else None),
+                         "frac_of_achievable": steady["achieved"] / probe if probe else None,
+                         "achieved_survey_8d_GBs": survey_unit * chunk * E * N / (kern_ms * 1e-3) / 1e9,
                          "survey_8d_bytes_per_agent_step": survey_unit},
         }
+        if secondary:
+            line["secondary"] = secondary
         if not args.no_cpu_baseline and world == 1 and args.workload == "c2" and args.policy == "random":
             line["cpu_baseline"] = cpu_baseline(config, N)
         elif world > 1:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
+    if direct:
+        direct.close()
     env.close()
     if world > 1:
         torch.distributed.destroy_process_group()
     return 0
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, argv)     # launcher only: no torch, no GPU in this process
+    if args.rehearse:
+        return rehearse(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":

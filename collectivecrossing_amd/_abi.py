@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # ccx_status
 OK, EINVAL, ENOMEM, EHIP, ENODEVICE = 0, -1, -2, -3, -4
@@ -105,9 +105,15 @@ PROTOTYPES: dict[str, tuple] = {
                               C.POINTER(CcxRolloutOut)]),
     "ccx_rollout_policy": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CcxRolloutOut),
                                      C.c_void_p]),
+    "ccx_set_check_inputs": (C.c_int, [_H, C.c_int32]),
+    "ccx_check_inputs": (C.c_int, [_H]),
     "ccx_zero_counters": (C.c_int, [_H]),
     "ccx_read_counters": (C.c_int, [_H, C.POINTER(CcxCounters)]),
     "ccx_counters_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    "ccx_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "ccx_rccl_comm_create": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "ccx_rccl_comm_destroy": (C.c_int, [C.c_void_p]),
+    "ccx_rccl_allreduce_counters": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "ccx_set_timing": (C.c_int, [_H, C.c_int32]),
     "ccx_last_launch_ms": (C.c_int, [_H, C.POINTER(C.c_float)]),
     "ccx_set_launch_shape": (C.c_int, [_H, C.c_int32, C.c_int32]),
@@ -115,6 +121,8 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_set_store_throttle": (C.c_int, [_H, C.c_int32]),
     "ccx_set_step_pace": (C.c_int, [_H, C.c_int32]),
     "ccx_get_step_pace": (C.c_int, [_H, C.POINTER(C.c_float)]),
+    "ccx_set_step_pace_start": (C.c_int, [_H, C.c_float]),
+    "ccx_set_tunable": (C.c_int, [_H, C.c_char_p, C.c_int32]),
     "ccx_get_residency": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccx_get_writer_shape": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccx_get_launch_shape": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

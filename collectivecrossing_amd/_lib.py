@@ -24,6 +24,11 @@ class CcxError(RuntimeError):
         self.status = status
 
 
+class CcxInputError(CcxError, ValueError):
+    """CCX_CHECK_INPUTS found action bytes / move orders the reference would have raised ``ValueError``
+    for (collectivecrossing.py:685-711)."""
+
+
 def load() -> C.CDLL:
     """dlopen libccx.so, bind and type every symbol of include/ccx.h, check the ABI version."""
     global _lib
@@ -52,4 +57,5 @@ def load() -> C.CDLL:
 def check(status: int) -> None:
     if status != _abi.OK:
         msg = load().ccx_last_error()
-        raise CcxError(status, msg.decode() if msg else "")
+        text = msg.decode() if msg else ""
+        raise (CcxInputError if text.startswith("invalid inputs") else CcxError)(status, text)

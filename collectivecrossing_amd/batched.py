@@ -13,7 +13,10 @@ reference is layered on top of this class in :mod:`.env`.
 from __future__ import annotations
 
 import ctypes as C
+import json
+import os
 from dataclasses import dataclass
+from pathlib import Path
 
 import numpy as np
 import torch
@@ -51,7 +54,7 @@ class BatchedCollectiveCrossing:
     """E envs sharing one config, resident on one GPU for their whole life."""
 
     def __init__(self, config: CollectiveCrossingConfig, num_envs: int, device: int | str | None = None,
-                 env_offset: int = 0, total_envs: int | None = None):
+                 env_offset: int = 0, total_envs: int | None = None, check_inputs: bool | None = None):
         self._lib = load()
         self.config = config
         self.params = lower_config(config)
@@ -76,10 +79,20 @@ class BatchedCollectiveCrossing:
         self._h = handle
         self._pool: torch.Tensor | None = None
         self._step_bufs: StepResult | None = None
+        self._rollouts_with_obs = 0
+        if check_inputs is None:
+            check_inputs = os.environ.get("CCX_CHECK_INPUTS", "0") not in ("", "0")
+        if check_inputs:
+            self.set_check_inputs(True)
+        self._apply_pace_memory()
 
     # ------------------------------------------------------------------ lifetime
     def close(self) -> None:
         if getattr(self, "_h", None):
+            try:
+                self._remember_pace()
+            except Exception:
+                pass
             self._lib.ccx_destroy(self._h)
             self._h = None
 
@@ -100,7 +113,22 @@ class BatchedCollectiveCrossing:
             t = torch.from_numpy(np.ascontiguousarray(a, np.uint8)).to(self.device)
         if tuple(t.shape) != tuple(shape):
             raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
-        return t.contiguous()
+        t = t.contiguous()
+        self._order_after_current_stream(t)
+        return t
+
+    def _order_after_current_stream(self, *tensors) -> None:
+        """The library launches on the stream captured at construction (or `use_stream`).  Inputs are
+        produced / copied on torch's CURRENT stream: when that is another stream, make the launch stream
+        wait for it and tell the caching allocator that the launch stream uses the buffers (otherwise
+        nothing orders the H2D copy before the kernel, and a temporary could be recycled while the
+        kernel still reads it)."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self._stream.cuda_stream:
+            self._stream.wait_stream(cur)
+            for t in tensors:
+                if t is not None and t.is_cuda:
+                    t.record_stream(self._stream)
 
     # ------------------------------------------------------------------ state
     def set_state(self, x=None, y=None, active=None, terminated=None, truncated=None,
@@ -243,6 +271,7 @@ class BatchedCollectiveCrossing:
             ro = _abi.CcxRolloutOut(_ptr(out.obs).value, _ptr(out.reward).value,
                                     _ptr(out.agent_flags).value, _ptr(out.env_flags).value)
             check(self._lib.ccx_rollout(self._h, K, _ptr(a), _ptr(o), int(bool(auto_reset)), C.byref(ro)))
+            self._rollouts_with_obs += int(out.obs is not None and K >= 64)
         else:
             check(self._lib.ccx_rollout(self._h, K, _ptr(a), _ptr(o), int(bool(auto_reset)), None))
         return out
@@ -261,6 +290,7 @@ class BatchedCollectiveCrossing:
                                 _ptr(out.agent_flags).value, _ptr(out.env_flags).value)
         check(self._lib.ccx_rollout_policy(self._h, K, _abi.POLICIES[policy], int(bool(auto_reset)),
                                            C.byref(ro), _ptr(actions_out)))
+        self._rollouts_with_obs += int(out.obs is not None and K >= 64)
         return out, actions_out
 
     # ------------------------------------------------------------------ counters / timing / shape
@@ -277,6 +307,71 @@ class BatchedCollectiveCrossing:
         p = C.c_void_p()
         check(self._lib.ccx_counters_device_ptr(self._h, C.byref(p)))
         return _device_view_i64(p.value, len(_abi.COUNTER_FIELDS), self.device)
+
+    def set_check_inputs(self, enabled: bool = True) -> None:
+        """Opt-in validation of action / move-order tensors on the device (``ccx_set_check_inputs``): what
+        the reference's ``_check_action_and_agent_validity`` raises on (collectivecrossing.py:685-711).
+        Violations surface as :class:`CcxInputError` (a ``ValueError``) from the next ``synchronize()``,
+        ``counters()`` or ``check_inputs()``.  Also enabled by ``CCX_CHECK_INPUTS=1``."""
+        check(self._lib.ccx_set_check_inputs(self._h, int(bool(enabled))))
+
+    def check_inputs(self) -> None:
+        """Synchronise and raise ``CcxInputError`` if a checked launch saw invalid actions / orders."""
+        check(self._lib.ccx_check_inputs(self._h))
+
+    def set_tunable(self, name: str, value: int) -> None:
+        """Performance experiment knobs (``ccx_set_tunable``); results never depend on them."""
+        check(self._lib.ccx_set_tunable(self._h, name.encode(), int(value)))
+
+    def set_step_pace_start(self, ns_per_env_step: float) -> None:
+        """Start value of the adaptive pace controller (``ccx_set_step_pace_start``), 0 = library default."""
+        check(self._lib.ccx_set_step_pace_start(self._h, float(ns_per_env_step)))
+
+    # -- pace memory: the adaptive controller needs ~30 launches to find the drain rate of a box; a handle
+    # of a shape seen before starts from what was learned (user cache first, then the values shipped in
+    # pace_defaults.json, measured on MI355X).  Never affects results.
+    _PACE_DEFAULTS = Path(__file__).resolve().parent / "pace_defaults.json"
+
+    @staticmethod
+    def _pace_cache_path() -> Path:
+        return Path(os.environ.get("CCX_PACE_CACHE") or Path.home() / ".cache" / "collectivecrossing_amd" / "pace.json")
+
+    def _pace_key(self) -> str:
+        s = self.launch_shape()
+        c = self.config
+        name = torch.cuda.get_device_properties(self.device).name
+        return (f"{name}|grid{c.width}x{c.height}|E{self.num_envs}|N{self.num_agents}|lanes{s['lanes_per_wave']}"
+                f"|tpb{s['waves_per_block']}|w{s['writers_per_tile']}")
+
+    def _apply_pace_memory(self) -> None:
+        if os.environ.get("CCX_PACE_MEMORY", "1") in ("", "0"):
+            return
+        key = self._pace_key()
+        for path in (self._pace_cache_path(), self._PACE_DEFAULTS):
+            try:
+                ns = float(json.loads(path.read_text())[key]["pace_ns"])
+            except Exception:
+                continue
+            if ns > 0:
+                self.set_step_pace_start(ns * 1.01)      # start a notch on the safe side of the remembered pace
+                return
+
+    def _remember_pace(self) -> None:
+        if self._rollouts_with_obs < 40 or os.environ.get("CCX_PACE_MEMORY", "1") in ("", "0"):
+            return
+        ns = self.step_pace_ns()
+        if not ns > 0:
+            return
+        path = self._pace_cache_path()
+        try:
+            data = json.loads(path.read_text())
+        except Exception:
+            data = {}
+        data[self._pace_key()] = {"pace_ns": round(ns, 2), "launches": self._rollouts_with_obs}
+        path.parent.mkdir(parents=True, exist_ok=True)
+        tmp = path.with_suffix(f".tmp{os.getpid()}")
+        tmp.write_text(json.dumps(data, indent=1, sort_keys=True))
+        tmp.replace(path)
 
     def set_timing(self, enabled: bool = True) -> None:
         """Record HIP events around every launch so that ``last_launch_ms`` works (off by default)."""

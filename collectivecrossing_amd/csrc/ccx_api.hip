@@ -13,8 +13,7 @@
 #include <new>
 #include <vector>
 
-#include "../../include/ccx.h"
-#include "ccx_kernels.h"
+#include "ccx_internal.h"
 
 namespace {
 
@@ -22,22 +21,6 @@ namespace {
 constexpr size_t kMaxObsUnits = 64u * (3u + 2u * 64u) + 2u;
 
 thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define CCX_HIP(call)                                                                         \
-    do {                                                                                      \
-        hipError_t e_ = (call);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(CCX_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),      \
-                        __FILE__, __LINE__);                                                  \
-    } while (0)
 
 int ceil_log2(int n) {
     int g = 0;
@@ -47,34 +30,16 @@ int ceil_log2(int n) {
 
 }  // namespace
 
-struct ccx_handle {
-    ccx_params params{};
-    int32_t E = 0, N = 0;
-    int64_t env_offset = 0, total_envs = 0;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    ccx::KState st{};
-    unsigned long long* cell_info = nullptr; // per-cell geometry table (see ccx_kernels.hip: CellInfo)
-    uint8_t* placement_scratch = nullptr;    // u8 [E][N][2] work area of ccx_reset_seeded
-    unsigned long long* counters = nullptr;  // 6 x u64 (+ 10 spare words used by diagnostic builds)
-    const uint8_t* pool = nullptr;
-    int64_t pool_size = 0;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool timed = false;
-    bool timing = false;                                       // record HIP events around launches
-    int lanes_per_wave = 0, waves_per_block = 0, writers = 0;  // user overrides (0 = default)
-    int store_throttle = 0;                                    // 0 = default, -1 = off, >0 = stores in flight
-    int step_pace_ns = 0;                                      // 0 = adaptive, -1 = off, >0 = fixed ns per env-step
-    uint32_t* pace_state = nullptr;                            // device: current pace (ticks x 256)
-    uint32_t pace_init_fp = 0;                                 // value to (re)start the controller from
-    bool pace_dirty = true;                                    // pace_state must be rewritten before a launch
-    uint16_t* obs_table = nullptr;                             // device: obs address table of the current shape
-    std::vector<uint16_t> obs_table_host;
-    uint32_t pace_slot = 0;                                    // slot of pace_state the next launch reads
-    int num_cus = 256;
-    ccx::LaunchShape shape{};
-    ccx::KParams kp{};
-};
+namespace ccxi {
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace ccxi
+using ccxi::fail;
 
 namespace {
 
@@ -126,7 +91,7 @@ std::vector<unsigned long long> build_cell_table(const ccx_params& p) {
 // EW is, so the batch should be cut into at least ~512 tiles (1024 waves = one per SIMD of the
 // 256 CUs) before tiles are made fuller.  Measured on 4096 envs x 8 agents: 64 lanes/wave
 // (512 tiles) 0.252 ms per 250 steps, 32 lanes 0.280 ms, 16 lanes 0.344 ms.
-void choose_shape(ccx_handle* h) {
+int choose_shape(ccx_handle* h) {
     const int glog = ceil_log2(h->N);
     const int G = 1 << glog;
     const int max_ew = 64 / G;
@@ -227,7 +192,7 @@ void choose_shape(ccx_handle* h) {
     // Step pacing (ccx_kernels.hip).  The schedule limits the rate at which the resident
     // workgroups inject observation stores; its start value assumes a drain rate of 6.8 TB/s and the
     // kernel retunes it after every long launch (bounds: 7.8 TB/s .. a sixth of the start rate).
-    (void)hipSetDevice(h->device);
+    CCX_HIP(hipSetDevice(h->device));
     int per_cu = ccx::rollout_blocks_per_cu(s, h->N);
     if (per_cu < 1) per_cu = 1;
     s.resident_blocks = std::min(s.num_blocks, per_cu * h->num_cus);
@@ -245,21 +210,29 @@ void choose_shape(ccx_handle* h) {
     // never happen inside a graph capture: wait for launches that still read the old table, then copy.
     h->obs_table_host.assign((size_t)units + 2u, 0);
     for (int w = 0; w < units; ++w) h->obs_table_host[(size_t)w] = ccx::obs_unit_addr((uint32_t)w, h->N, glog);
-    (void)hipStreamSynchronize(h->stream);
-    if (hipMemcpy(h->obs_table, h->obs_table_host.data(), h->obs_table_host.size() * sizeof(uint16_t),
-                  hipMemcpyHostToDevice) != hipSuccess)
-        (void)hipGetLastError();   // surfaces as a wrong-result test failure rather than silently: see ccx_create
+    CCX_HIP(hipStreamSynchronize(h->stream));
+    CCX_HIP(hipMemcpy(h->obs_table, h->obs_table_host.data(), h->obs_table_host.size() * sizeof(uint16_t),
+                      hipMemcpyHostToDevice));
     k.obs_table = h->obs_table;
     k.pace_min_fp = to_fp(s.step_bytes / 7800.0);
     k.pace_max_fp = to_fp(s.step_bytes / 1100.0);
-    h->pace_init_fp = h->step_pace_ns > 0 ? to_fp((double)h->step_pace_ns) : to_fp(s.step_bytes / 6800.0);
+    h->pace_init_fp = h->step_pace_ns > 0 ? to_fp((double)h->step_pace_ns)
+                      : h->pace_start_ns > 0.0f ? to_fp((double)h->pace_start_ns) : to_fp(s.step_bytes / 6800.0);
     h->pace_dirty = true;
     k.r_dest = p.boarding_destination_reward; k.r_door = p.tram_door_reward;
     k.r_area = p.tram_area_reward; k.r_f = p.distance_penalty_factor;
     k.r_nogoal = p.no_goal_reward; k.r_pen = p.step_penalty;
     k.env_offset = h->env_offset;
     k.pool_size = h->pool_size;
+    // cursor stride of the reset pool: entry (global_env + episode * stride) mod P.  total_envs mod P keeps
+    // the walk independent of the world size; when P divides total_envs that would be 0 and every env
+    // would restart from ONE placement forever, so the stride is 1 then (env e walks e, e+1, e+2, ...)
     k.pool_stride = h->pool_size > 0 ? (long long)(h->total_envs % h->pool_size) : 0;
+    if (h->pool_size > 0 && k.pool_stride == 0) k.pool_stride = 1 % h->pool_size;
+    k.pace_phase = (uint32_t)h->tun_pace_phase;
+    k.tile_map = (uint32_t)h->tun_tile_map;
+    k.writer_gap = (uint32_t)h->tun_writer_gap;
+    return CCX_OK;
 }
 
 int validate_params(const ccx_params* p) {
@@ -308,6 +281,11 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
         h->pace_dirty = false;
     }
     h->kp.pace_slot = h->pace_slot;
+    if (h->check_inputs && actions) {
+        hipError_t ce = ccx::launch_check_inputs(h->stream, actions, order, (size_t)K * (size_t)h->E, h->N,
+                                                 h->input_errors);
+        if (ce != hipSuccess) return fail(CCX_EHIP, "input check kernel launch failed: %s", hipGetErrorString(ce));
+    }
     int rc = begin_timed(h);
     if (rc) return rc;
     hipError_t e = ccx::launch_rollout(h->shape, h->stream, h->kp, h->st, h->cell_info, actions,
@@ -326,7 +304,7 @@ int ccx_abi_version(void) { return CCX_ABI_VERSION; }
 
 const char* ccx_build_info(void) {
     static char buf[128];
-    snprintf(buf, sizeof(buf), "libccx 0.2.0 abi %d gfx950 hip %d.%d", CCX_ABI_VERSION,
+    snprintf(buf, sizeof(buf), "libccx 0.3.0 abi %d gfx950 hip %d.%d", CCX_ABI_VERSION,
              HIP_VERSION_MAJOR, HIP_VERSION_MINOR);
     return buf;
 }
@@ -384,6 +362,7 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     alloc((void**)&h->counters, ccx::counter_words(h->E) * sizeof(unsigned long long));
     alloc((void**)&h->placement_scratch, en * 2);
     alloc((void**)&h->pace_state, 4 * sizeof(uint32_t));
+    alloc((void**)&h->input_errors, 2 * sizeof(unsigned long long));
     alloc((void**)&h->obs_table, kMaxObsUnits * sizeof(uint16_t));
     if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess ||
         h->num_cus < 1)
@@ -404,13 +383,18 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     if (e == hipSuccess) e = hipMemsetAsync(h->st.episode, 0, (size_t)h->E * 4, h->stream);
     if (e == hipSuccess)
         e = hipMemsetAsync(h->counters, 0, ccx::counter_words(h->E) * sizeof(unsigned long long), h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->input_errors, 0, 2 * sizeof(unsigned long long), h->stream);
     if (e != hipSuccess) {
         int code = (e == hipErrorOutOfMemory) ? CCX_ENOMEM : CCX_EHIP;
         fail(code, "ccx_create: %s", hipGetErrorString(e));
         ccx_destroy(h);
         return code;
     }
-    choose_shape(h);
+    rc = choose_shape(h);
+    if (rc) {
+        ccx_destroy(h);
+        return rc;
+    }
     *out = h;
     return CCX_OK;
 }
@@ -428,6 +412,7 @@ void ccx_destroy(ccx_handle* h) {
     (void)hipFree(h->st.episode);
     (void)hipFree(h->counters);
     (void)hipFree(h->pace_state);
+    (void)hipFree(h->input_errors);
     (void)hipFree(h->obs_table);
     (void)hipFree(h->cell_info);
     (void)hipFree(h->placement_scratch);
@@ -511,8 +496,7 @@ int ccx_set_reset_pool(ccx_handle* h, const uint8_t* pool_xy, int64_t pool_size)
     if (reinterpret_cast<uintptr_t>(pool_xy) & 1u) return fail(CCX_EINVAL, "pool must be 2-byte aligned");
     h->pool = pool_xy;
     h->pool_size = pool_size;
-    choose_shape(h);
-    return CCX_OK;
+    return choose_shape(h);
 }
 
 int ccx_reset_from_pool(ccx_handle* h, const uint8_t* env_mask) {
@@ -632,6 +616,34 @@ int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t
     return run_rollout(h, num_steps, nullptr, nullptr, auto_reset ? 1 : 0, ko, policy, actions_out);
 }
 
+namespace {
+// CCX_CHECK_INPUTS: after a stream sync, turn what check_inputs_kernel counted into CCX_EINVAL (once)
+int report_input_errors(ccx_handle* h) {
+    if (!h->check_inputs) return CCX_OK;
+    unsigned long long bad[2] = {0, 0};
+    CCX_HIP(hipMemcpy(bad, h->input_errors, sizeof(bad), hipMemcpyDeviceToHost));
+    if (!bad[0] && !bad[1]) return CCX_OK;
+    CCX_HIP(hipMemset(h->input_errors, 0, sizeof(bad)));
+    return fail(CCX_EINVAL, "invalid inputs since the last check: Invalid action: %llu action byte(s) outside "
+                "{0,1,2,3,4} and not CCX_ACTION_ABSENT; Unknown agent ID / duplicate: %llu move-order row(s) that are "
+                "not a permutation of 0..N-1 (collectivecrossing.py:685-711); such entries were stepped as "
+                "'no move' / an undefined order", bad[0], bad[1]);
+}
+}  // namespace
+
+int ccx_set_check_inputs(ccx_handle* h, int32_t enabled) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    h->check_inputs = enabled != 0;
+    return CCX_OK;
+}
+
+int ccx_check_inputs(ccx_handle* h) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    CCX_HIP(hipSetDevice(h->device));
+    CCX_HIP(hipStreamSynchronize(h->stream));
+    return report_input_errors(h);
+}
+
 int ccx_zero_counters(ccx_handle* h) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");
     CCX_HIP(hipSetDevice(h->device));
@@ -646,7 +658,7 @@ int ccx_read_counters(ccx_handle* h, ccx_counters* out_host) {
     CCX_HIP(ccx::launch_reduce_counters(h->stream, h->counters, h->E));
     CCX_HIP(hipStreamSynchronize(h->stream));
     CCX_HIP(hipMemcpy(out_host, h->counters, sizeof(ccx_counters), hipMemcpyDeviceToHost));
-    return CCX_OK;
+    return report_input_errors(h);
 }
 
 int ccx_counters_device_ptr(ccx_handle* h, uint64_t** out) {
@@ -682,16 +694,14 @@ int ccx_set_launch_shape(ccx_handle* h, int32_t lanes_per_wave, int32_t waves_pe
     if (waves_per_block < 0 || waves_per_block > 4) return fail(CCX_EINVAL, "waves_per_block must be 0..4");
     h->lanes_per_wave = lanes_per_wave;
     h->waves_per_block = waves_per_block;
-    choose_shape(h);
-    return CCX_OK;
+    return choose_shape(h);
 }
 
 int ccx_set_writers(ccx_handle* h, int32_t writers_per_tile) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");
     if (writers_per_tile < 0 || writers_per_tile > 7) return fail(CCX_EINVAL, "writers_per_tile must be 0..7");
     h->writers = writers_per_tile;
-    choose_shape(h);
-    return CCX_OK;
+    return choose_shape(h);
 }
 
 int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight) {
@@ -699,16 +709,39 @@ int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight) {
     if (max_stores_in_flight < -1 || max_stores_in_flight > 63)
         return fail(CCX_EINVAL, "max_stores_in_flight must be -1 (off), 0 (default) or 1..63");
     h->store_throttle = max_stores_in_flight;
-    choose_shape(h);
-    return CCX_OK;
+    return choose_shape(h);
 }
 
 int ccx_set_step_pace(ccx_handle* h, int32_t ns_per_env_step) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");
     if (ns_per_env_step < -1) return fail(CCX_EINVAL, "ns_per_env_step must be -1 (off), 0 (adaptive) or > 0");
     h->step_pace_ns = ns_per_env_step;
-    choose_shape(h);
-    return CCX_OK;
+    return choose_shape(h);
+}
+
+int ccx_set_step_pace_start(ccx_handle* h, float ns_per_env_step) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if (!(ns_per_env_step >= 0.0f) || ns_per_env_step > 1.0e7f)
+        return fail(CCX_EINVAL, "ns_per_env_step must be 0 (library default) or a positive number of nanoseconds");
+    h->pace_start_ns = ns_per_env_step;
+    return choose_shape(h);
+}
+
+int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
+    if (!h || !name) return fail(CCX_EINVAL, "NULL argument");
+    struct { const char* name; int* slot; int lo, hi; } table[] = {
+        {"pace_phase", &h->tun_pace_phase, 0, 2},
+        {"tile_map", &h->tun_tile_map, 0, 1},
+        {"writer_gap", &h->tun_writer_gap, 0, 64},
+    };
+    for (auto& t : table)
+        if (strcmp(name, t.name) == 0) {
+            if (value < t.lo || value > t.hi)
+                return fail(CCX_EINVAL, "tunable %s must be %d..%d (got %d)", name, t.lo, t.hi, value);
+            *t.slot = value;
+            return choose_shape(h);
+        }
+    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, writer_gap)", name);
 }
 
 int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {
@@ -778,7 +811,7 @@ int ccx_synchronize(ccx_handle* h) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");
     CCX_HIP(hipSetDevice(h->device));
     CCX_HIP(hipStreamSynchronize(h->stream));
-    return CCX_OK;
+    return report_input_errors(h);
 }
 
 }  // extern "C"

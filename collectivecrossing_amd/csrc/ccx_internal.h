@@ -1,0 +1,58 @@
+// ccx_internal.h -- what the translation units of the C-ABI layer share (not installed, not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/ccx.h"
+#include "ccx_kernels.h"
+
+namespace ccxi {
+
+// records the thread-local message returned by ccx_last_error() and hands the code back
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+}  // namespace ccxi
+
+#define CCX_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return ccxi::fail(CCX_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                              __FILE__, __LINE__);                                            \
+    } while (0)
+
+struct ccx_handle {
+    ccx_params params{};
+    int32_t E = 0, N = 0;
+    int64_t env_offset = 0, total_envs = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ccx::KState st{};
+    unsigned long long* cell_info = nullptr; // per-cell geometry table (see ccx_kernels.hip: CellInfo)
+    uint8_t* placement_scratch = nullptr;    // u8 [E][N][2] work area of ccx_reset_seeded
+    unsigned long long* counters = nullptr;  // 6 x u64 (+ 10 spare words used by diagnostic builds)
+    const uint8_t* pool = nullptr;
+    int64_t pool_size = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    bool timing = false;                                       // record HIP events around launches
+    int lanes_per_wave = 0, waves_per_block = 0, writers = 0;  // user overrides (0 = default)
+    int store_throttle = 0;                                    // 0 = default, -1 = off, >0 = stores in flight
+    int step_pace_ns = 0;                                      // 0 = adaptive, -1 = off, >0 = fixed ns per env-step
+    uint32_t* pace_state = nullptr;                            // device: current pace (ticks x 256)
+    uint32_t pace_init_fp = 0;                                 // value to (re)start the controller from
+    bool pace_dirty = true;                                    // pace_state must be rewritten before a launch
+    uint16_t* obs_table = nullptr;                             // device: obs address table of the current shape
+    std::vector<uint16_t> obs_table_host;
+    uint32_t pace_slot = 0;                                    // slot of pace_state the next launch reads
+    int num_cus = 256;
+    float pace_start_ns = 0.0f;                                // > 0: the adaptive controller starts here (ccx_set_step_pace_start)
+    int tun_pace_phase = 0, tun_tile_map = 0, tun_writer_gap = 0;   // ccx_set_tunable
+    bool check_inputs = false;                                 // ccx_set_check_inputs
+    unsigned long long* input_errors = nullptr;                // device [2]: bad action bytes, bad order rows
+    ccx::LaunchShape shape{};
+    ccx::KParams kp{};
+};

@@ -41,7 +41,10 @@ struct KParams {
     double r_dest, r_door, r_area, r_f, r_nogoal, r_pen;
     long long env_offset;                // global index of env 0 (sharding)
     long long pool_size;                 // reset-pool entries (0 = none)
-    long long pool_stride;               // total_envs mod pool_size
+    long long pool_stride;               // cursor stride: total_envs mod pool_size, 1 when that is 0
+    // tunables (ccx_set_tunable): how the tiles' step schedules are phased, how workgroups map to tiles,
+    // pause between a writer's store iterations
+    uint32_t pace_phase, tile_map, writer_gap;
 };
 
 struct KState {
@@ -111,6 +114,10 @@ hipError_t launch_observe(const LaunchShape& ls, hipStream_t stream, const KPara
 hipError_t launch_reset_from_pool(hipStream_t stream, const KParams& p, const KState& st,
                                   const uint8_t* env_mask, const uint8_t* pool);
 
+// CCX_CHECK_INPUTS: counts action bytes outside {0..4, 255} into bad[0] and move-order rows that are not a
+// permutation of 0..N-1 into bad[1] (collectivecrossing.py:685-711), one thread per (step, env) row
+hipError_t launch_check_inputs(hipStream_t stream, const uint8_t* actions, const uint8_t* order, size_t rows,
+                               int N, unsigned long long* bad);
 hipError_t launch_greedy_actions(hipStream_t stream, const KParams& p, const KState& st,
                                  const unsigned long long* cell_info, uint8_t* actions, int policy);
 hipError_t launch_seeded_placement(hipStream_t stream, const KParams& p, int n, const uint64_t* seeds,

@@ -298,12 +298,11 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     // writes one contiguous eighth of every step's output slab instead of every eighth chunk --
     // the pace at which the output stream collapses moves from ~740 to ~700 ns per env-step on C2
     // (profiles/scratch/tile_times.py).
-#ifdef CCX_LINEAR_TILES   // diagnostic: the plain blockIdx -> tile mapping
-    const int bid = blockIdx.x;
-#else
-    const int nb = gridDim.x, xcd = blockIdx.x & 7, q8 = nb >> 3, r8 = nb & 7;
-    const int bid = xcd * q8 + (xcd < r8 ? xcd : r8) + (int)(blockIdx.x >> 3);
-#endif
+    int bid = blockIdx.x;     // tunable tile_map = 1: the plain blockIdx -> tile mapping
+    if (!p.tile_map) {
+        const int nb = gridDim.x, xcd = blockIdx.x & 7, q8 = nb >> 3, r8 = nb & 7;
+        bid = xcd * q8 + (xcd < r8 ? xcd : r8) + (int)(blockIdx.x >> 3);
+    }
     const int tile = bid * tpb + tile_in_block;
     const int g = lane >> GLOG;
     const int i = lane & (G - 1);
@@ -498,6 +497,8 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                                     }
                                 }
                             }
+                            // tunable: spread a writer's store iterations over the step period
+                            for (uint32_t z = 0; z < p.writer_gap; ++z) __builtin_amdgcn_s_sleep(2);
                         }
                     }
                     // beyond the register-cached iterations: table-driven
@@ -655,6 +656,17 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             p.pace_state[3] = streak < 1000u ? streak + 1u : streak;
         }
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pace_t0)::"memory");
+        if (p.pace_phase) {
+            // tunable: the tiles of a round do not start their steps together but spread over the step
+            // period -- 1: in tile order (the chip then writes one narrow window that sweeps through the
+            // step's slab), 2: hashed.  Only the tile's own t0 moves; the schedule and the controller's
+            // lateness test are relative to it.
+            const uint32_t per_round = (p.resident_blocks ? p.resident_blocks : gridDim.x) * (uint32_t)tpb;
+            const uint32_t tr = (uint32_t)tile % per_round;
+            const uint32_t frac16 = p.pace_phase == 1u ? (tr << 16) / per_round
+                                                       : (__brev(tr * 2654435761u) & 0xFFFFu);
+            pace_t0 += ((unsigned long long)pace * frac16) >> 24;
+        }
     }
 
     int s = 0;

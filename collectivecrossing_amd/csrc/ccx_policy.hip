@@ -76,4 +76,47 @@ hipError_t launch_greedy_actions(hipStream_t stream, const KParams& p, const KSt
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// CCX_CHECK_INPUTS (opt-in): what the reference's _check_action_and_agent_validity raises on
+// (collectivecrossing.py:685-711: action not in 0..4, agent id not in the env), restated for the array
+// inputs of ccx_step / ccx_rollout: an action byte must be 0..4 or CCX_ACTION_ABSENT, a move-order row
+// must name every slot exactly once.  Counted here, reported as CCX_EINVAL by the next synchronising
+// call; a separate elementwise kernel so that the hot kernel carries none of it.
+// ---------------------------------------------------------------------------------------------
+__global__ void check_inputs_kernel(const uint8_t* __restrict__ actions, const uint8_t* __restrict__ order,
+                                    const size_t rows, const int N, unsigned long long* bad) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bad_a = 0, bad_o = 0;
+    if (r < rows) {
+        const uint8_t* a = actions + r * (size_t)N;
+        for (int i = 0; i < N; ++i) bad_a += (a[i] > 4u && a[i] != (uint8_t)CCX_K_ABSENT) ? 1u : 0u;
+        if (order) {
+            const uint8_t* o = order + r * (size_t)N;
+            unsigned long long seen = 0;
+            for (int i = 0; i < N; ++i) {
+                const uint32_t v = o[i];
+                if (v >= (uint32_t)N || ((seen >> v) & 1ull)) bad_o = 1u;
+                else seen |= 1ull << v;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bad_a += __shfl_xor(bad_a, off, 64);
+        bad_o += __shfl_xor(bad_o, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad_a) atomicAdd(&bad[0], (unsigned long long)bad_a);
+        if (bad_o) atomicAdd(&bad[1], (unsigned long long)bad_o);
+    }
+}
+
+hipError_t launch_check_inputs(hipStream_t stream, const uint8_t* actions, const uint8_t* order, size_t rows,
+                               int N, unsigned long long* bad) {
+    if (rows == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((rows + 255) / 256);
+    hipLaunchKernelGGL(check_inputs_kernel, dim3(blocks), dim3(256), 0, stream, actions, order, rows, N, bad);
+    return hipGetLastError();
+}
+
 }  // namespace ccx

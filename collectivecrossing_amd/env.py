@@ -173,15 +173,28 @@ class CollectiveCrossingEnv(_Base):
         self._setup_spaces()
         if _Base is not object:
             super().__init__()
+        # Strategies without a kernel_mode are user-registered Python classes (rewards.py:186-216,
+        # terminateds.py:86-114, truncateds.py:99-128, observations.py:122-149 accept any registered
+        # class).  The GPU then runs the move / deactivate phases with built-in stand-ins for them and
+        # step() evaluates the user's strategies on the host mirror in the reference's phase order
+        # (_step_host_strategies: the documented slow path).
+        self._host_strategies = any(fn.kernel_mode is None for fn in (
+            self._reward_function, self._terminated_function, self._truncated_function,
+            self._observation_function))
         gpu_config = config
-        if self._reward_function.kernel_mode is None:
-            # user-registered reward: the kernel computes the default reward, step() overrides it
-            from .configs import DefaultRewardConfig
-            gpu_config = config.model_copy(update={"reward_config": DefaultRewardConfig()})
-        for fn, what in ((self._terminated_function, "termination"), (self._truncated_function, "truncation")):
-            if fn.kernel_mode is None:
-                raise NotImplementedError(f"user-defined {what} strategies change the state transition and "
-                                          "are not supported by the GPU step")
+        if self._host_strategies:
+            from .configs import (DefaultObservationConfig, DefaultRewardConfig,
+                                  IndividualAtDestinationTerminatedConfig, MaxStepsTruncatedConfig)
+            update = {}
+            if self._reward_function.kernel_mode is None:
+                update["reward_config"] = DefaultRewardConfig()
+            if self._terminated_function.kernel_mode is None:
+                update["terminated_config"] = IndividualAtDestinationTerminatedConfig()
+            if self._truncated_function.kernel_mode is None:
+                update["truncated_config"] = MaxStepsTruncatedConfig()
+            if self._observation_function.kernel_mode is None:
+                update["observation_config"] = DefaultObservationConfig()
+            gpu_config = config.model_copy(update=update)
         # _host_view: no GPU handle -- only the host mirror and the predicates / strategy objects on
         # it (inspect recorded states, drive host-side policies); reset() and step() need the GPU
         self._batch = None if _host_view else BatchedCollectiveCrossing(gpu_config, 1, device=device)
@@ -362,6 +375,8 @@ class CollectiveCrossingEnv(_Base):
         b.synchronize()
         obs, ef = self._h_obs.copy(), int(self._h_ef[0])
         flags, rew = self._h_af.tolist(), self._h_rew.tolist()
+        if self._host_strategies:
+            return self._step_host_strategies(obs, flags, rew)
         # the new state is fully determined by the outputs: no state read-back; the mirror arrays are
         # brought up to date lazily (see _Mirror), only the flag lists are maintained per step
         m = self._mirror
@@ -395,23 +410,68 @@ class CollectiveCrossingEnv(_Base):
         m.defer(obs, act_l, term_l, trunc_l)
         m.step_count += 1
         self._agents_truncated_or_terminated_this_step = new_done
-        out = (observations, rewards, terminateds, truncateds, infos)
-        out = self._apply_custom_strategies(out)
-        return out
+        return observations, rewards, terminateds, truncateds, infos
 
-    def _apply_custom_strategies(self, out):
-        """User-registered strategies (no kernel_mode): evaluate on the synced mirror (slow path)."""
-        observations, rewards, terminateds, truncateds, infos = out
-        if self._reward_function.kernel_mode is None:
-            for aid in list(rewards):
+    def _step_host_strategies(self, obs, flags, rew):
+        """Slow path for user-registered strategies: the GPU has done the moves and the deactivation
+        (collectivecrossing.py:197-212, the O(N^2) part); phases :214-259 run here on the host mirror
+        in the reference's order -- rewards, terminated and truncated are all evaluated against the
+        PRE-step flags (a reward written as `if agent.terminated: return None` still pays on the step
+        the agent finishes), then the flags are applied once, then observations / infos are emitted
+        for `agents | finished this step`.  Built-in strategies keep the GPU's values (rewards: the
+        f64 from the kernel; observations: the kernel's rows); built-in terminated / truncated rules
+        are evaluated through their host methods so that any mix with user classes sees one state.
+        The GPU's own flag state is overwritten from the mirror before the next launch."""
+        m = self._mirror
+        ids, n = self._ids, len(self._ids)
+        m._pending = None
+        xy = obs[:, :2].astype(np.int32)
+        m.x[:], m.y[:] = xy[:, 0], xy[:, 1]
+        m.active[:] = [(f >> 6) & 1 for f in flags]
+        m.step_count += 1                                        # :188 (the kernel counted it too)
+        m.touch()
+        rewards, terminateds, truncateds = {}, {}, {}
+        gpu_reward = self._reward_function.kernel_mode is not None
+        for i, aid in enumerate(ids):                            # :214-217
+            if gpu_reward:
+                if flags[i] & 4:                                 # CCX_AF_LIVE = not done before the step
+                    rewards[aid] = rew[i]
+            else:
                 r = self._reward_function.calculate_reward(aid, self)
-                if r is None:
-                    rewards.pop(aid)
-                else:
+                if r is not None:
                     rewards[aid] = r
-        if self._observation_function.kernel_mode is None:
-            for aid in observations:
-                observations[aid] = self._observation_function.get_agent_observation(aid, self)
+        for aid in ids:                                          # :219-222
+            t = self._terminated_function.calculate_terminated(aid, self)
+            if t is not None:
+                terminateds[aid] = t
+        for aid in ids:                                          # :224-227
+            t = self._truncated_function.calculate_truncated(aid, self)
+            if t is not None:
+                truncateds[aid] = t
+        new_done = set()
+        for i, aid in enumerate(ids):                            # :229-241
+            if terminateds.get(aid) and not m.terminated[i]:
+                m.terminated[i] = 1
+                new_done.add(aid)
+        for i, aid in enumerate(ids):
+            if truncateds.get(aid) and not m.truncated[i]:
+                m.truncated[i] = 1
+                new_done.add(aid)
+        m.dirty = True                                           # the GPU applied the stand-in rules
+        m.touch()
+        self._agents_truncated_or_terminated_this_step = new_done
+        observations, infos = {}, {}
+        gpu_obs = self._observation_function.kernel_mode is not None
+        types = self._type_names
+        for i, aid in enumerate(ids):                            # :243-254
+            if (m.terminated[i] or m.truncated[i]) and aid not in new_done:
+                continue
+            observations[aid] = obs[i] if gpu_obs else self._observation_function.get_agent_observation(aid, self)
+            f = flags[i]
+            infos[aid] = {"agent_type": types[i], "in_tram_area": (f & 0x10) != 0, "at_door": (f & 0x20) != 0,
+                          "active": (f & 0x40) != 0, "at_destination": (f & 0x80) != 0}
+        terminateds["__all__"] = all(terminateds.values()) if terminateds else False   # :256-259
+        truncateds["__all__"] = all(truncateds.values()) if truncateds else False
         return observations, rewards, terminateds, truncateds, infos
 
     def close(self) -> None:

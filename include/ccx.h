@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CCX_ABI_VERSION 2
+#define CCX_ABI_VERSION 3
 
 typedef enum ccx_status {
     CCX_OK = 0,
@@ -142,8 +142,9 @@ int32_t ccx_obs_len(int32_t num_agents);
  * Create a batch of num_envs independent environments on `device`, using HIP stream `stream`
  * (a hipStream_t passed as void*; NULL = the device's default stream).  env_offset is the global
  * index of this handle's env 0 and total_envs the global batch size (multi-GPU sharding: the
- * reset-pool entry of env e, episode j is (env_offset + e + j*total_envs) mod pool_size, so the
- * trajectory of a global env does not depend on how many GPUs the batch is split over).
+ * reset-pool entry of env e, episode j depends on env_offset + e, j, total_envs and the pool size only
+ * (see ccx_set_reset_pool), so the trajectory of a global env does not depend on how many GPUs the
+ * batch is split over).
  * Replaces CollectiveCrossingEnv.__init__ (collectivecrossing.py:44-89) for E instances.
  * All agents start at (0,0), active, step_count 0: call ccx_set_state / ccx_reset_from_pool next.
  */
@@ -170,6 +171,9 @@ int ccx_get_state_host(ccx_handle* h, ccx_state* dst);
  * Reset pool: P seeded initial placements, u8 xy pairs [P][N][2], produced on the host by the
  * reference's rejection-sampling reset (collectivecrossing.py:91-150) for seeds seed0..seed0+P-1.
  * Device pointer; the library keeps the pointer (caller keeps the allocation alive).
+ * Cursor: env e (global index g = env_offset + e) starts episode j from entry (g + j * stride) mod P
+ * with stride = total_envs mod P, or 1 when P divides total_envs (so that every env still walks
+ * through the pool instead of restarting from one placement forever).
  */
 int ccx_set_reset_pool(ccx_handle* h, const uint8_t* pool_xy, int64_t pool_size);
 
@@ -233,12 +237,49 @@ int ccx_rollout(ccx_handle* h, int32_t num_steps, const uint8_t* actions, const 
 int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t auto_reset,
                        const ccx_rollout_out* out, uint8_t* actions_out);
 
+/*
+ * Opt-in input validation for the array API (the dict API validates on the host).  The reference raises
+ * ValueError for an action outside 0..4 and for an agent id the env does not have
+ * (_check_action_and_agent_validity, collectivecrossing.py:685-711); ccx_step / ccx_rollout by default
+ * treat any action byte other than 0..3 as "no move" and trust `order` to be a permutation.  With
+ * checking enabled every launch that takes an action tensor is preceded by an elementwise kernel that
+ * counts action bytes outside {0..4, CCX_ACTION_ABSENT} and move-order rows that are not a permutation
+ * of 0..N-1; the next synchronising call (ccx_synchronize, ccx_read_counters, ccx_check_inputs) then
+ * fails ONCE with CCX_EINVAL and a message naming both counts ("Invalid action", "Unknown agent ID").
+ * The offending entries have been stepped as "no move" / an undefined order by then: a caller that
+ * gets the error must discard those envs.  Costs one extra read of the action tensor (1 of 16N+34
+ * bytes per agent-step).
+ */
+int ccx_set_check_inputs(ccx_handle* h, int32_t enabled);
+int ccx_check_inputs(ccx_handle* h);     /* synchronises; CCX_EINVAL if anything was counted */
+
 int ccx_zero_counters(ccx_handle* h);
 int ccx_read_counters(ccx_handle* h, ccx_counters* out_host);   /* synchronous */
 /* device pointer to the 6 u64 counters (for an RCCL all-reduce by the caller).  The rollout kernel
  * accumulates per-tile partial counters; this call enqueues their reduction on the handle's stream, so
  * the totals cover every launch enqueued BEFORE it (call it again after later launches). */
 int ccx_counters_device_ptr(ccx_handle* h, uint64_t** out);
+
+/*
+ * The one collective of the multi-GPU layout, on RCCL directly: contiguous env shards never
+ * exchange data; once per measurement window the six u64 counters are summed over the ranks.
+ * ccx_rccl_allreduce_counters enqueues, on the handle's stream, the reduction of the per-tile partial
+ * counters and ONE ncclAllReduce(ncclSum, 6 x u64) over `rccl_comm` (an ncclComm_t passed as void*)
+ * into out_device (device memory, 6 x u64); *num_ranks (may be NULL) receives the communicator size.
+ * The handle's own counters keep the per-rank values.  The communicator is the caller's: either one it
+ * already has, or one made with the helpers below (rank 0 draws the 128-byte unique id, ships it to the
+ * other ranks by any means -- bench.py uses the torch.distributed store -- and every rank calls
+ * ccx_rccl_comm_create with the device its handle lives on).  librccl.so.1 is bound at run time; without
+ * it these calls fail with CCX_ENODEVICE and everything else keeps working.
+ * No reference counterpart: its parallelism is one env per RLlib EnvRunner process
+ * (examples/training_script.py:84).
+ */
+#define CCX_RCCL_UNIQUE_ID_BYTES 128
+int ccx_rccl_unique_id(void* id_out_128 /* host */);
+int ccx_rccl_comm_create(int32_t num_ranks, const void* id_128 /* host */, int32_t rank, int32_t device,
+                         void** comm_out);
+int ccx_rccl_comm_destroy(void* comm);
+int ccx_rccl_allreduce_counters(ccx_handle* h, void* rccl_comm, uint64_t* out_device, int32_t* num_ranks);
 
 /* Launch timing, off by default (two event records per launch cost a step-wise loop several
  * microseconds per step): when enabled, HIP events are recorded on the handle's stream around every
@@ -267,6 +308,16 @@ int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight);
  * ccx_get_step_pace returns the pace in effect (synchronises).  Results never depend on it. */
 int ccx_set_step_pace(ccx_handle* h, int32_t ns_per_env_step);
 int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step);
+/* Where the ADAPTIVE controller starts (ns per env-step; 0 = the library's assumption of 6.8 TB/s): a
+ * caller that remembers the pace a previous handle of the same shape converged to (ccx_get_step_pace)
+ * skips the descent of the first launches.  Restarts the controller. */
+int ccx_set_step_pace_start(ccx_handle* h, float ns_per_env_step);
+/* Performance experiments without an ABI change; results never depend on a tunable.
+ *   "pace_phase"  0 = every tile starts env-step s at t0 + s * pace (default), 1 = tiles are phased over
+ *                 the step period in tile order, 2 = hashed phases
+ *   "tile_map"    0 = workgroups of one XCD take adjacent tiles (default), 1 = tile = workgroup index
+ *   "writer_gap"  pause (x ~128 clocks) after each batch of a writer's observation stores, 0..64 */
+int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value);
 /* workgroups of a rollout launch with outputs, and how many of them the device holds at once (a grid
  * larger than that runs in rounds; the pace of a partial last round is scaled accordingly) */
 int ccx_get_residency(ccx_handle* h, int32_t* resident_workgroups, int32_t* workgroups);

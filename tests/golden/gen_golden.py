@@ -303,7 +303,8 @@ def run_scenarios(name, cfg, scenarios):
 
 
 def run_rollout(name, cfg, E, K, P, seed0, total_envs=None, env_offset=0):
-    """Auto-reset rollout: `if __all__: reset(seed=seed0 + (g + episode*total) % P)`."""
+    """Auto-reset rollout: `if __all__: reset(seed=seed0 + (g + episode*stride) % P)` with
+    stride = total % P, or 1 when P divides total (every env still walks through the pool)."""
     from collectivecrossing import CollectiveCrossingEnv
     total = total_envs or E
     ids = ids_of(cfg)
@@ -330,7 +331,7 @@ def run_rollout(name, cfg, E, K, P, seed0, total_envs=None, env_offset=0):
             at, au = rec.step(s, e, acts)
             if at or au:
                 episodes[e] += 1
-                env.reset(seed=seed0 + int((g + int(episodes[e]) * total) % P))
+                env.reset(seed=seed0 + int((g + int(episodes[e]) * ((total % P) or 1)) % P))
                 rec.a["env_flags"][s, e] |= EF["RESET"]
     rec.save(name, pool_xy=pool, seed0=np.int64(seed0), final_episode=episodes,
              total_envs=np.int64(total), env_offset=np.int64(env_offset))
@@ -416,6 +417,56 @@ def edge_scenarios():
     return cfg, sc
 
 
+def run_custom_strategies():
+    """g12_custom_strategies.json.gz: user-registered reward / terminated / truncated classes
+    (custom_strategies.py) stepped through the imported reference, every dict recorded as data."""
+    import custom_strategies as cs
+    from collectivecrossing import CollectiveCrossingEnv, configs, reward_configs, rewards
+    from collectivecrossing import terminated_configs, terminateds, truncated_configs, truncateds
+
+    plugins = cs.make(rewards.RewardFunction, terminateds.TerminatedFunction, truncateds.TruncatedFunction)
+    rewards.REWARD_FUNCTIONS[cs.NAMES["reward"]] = plugins["reward"]
+    terminateds.TERMINATED_FUNCTIONS[cs.NAMES["terminated"]] = plugins["terminated"]
+    truncateds.TRUNCATED_FUNCTIONS[cs.NAMES["truncated"]] = plugins["truncated"]
+    out = {}
+    for mix_name, mix in cs.MIXES.items():
+        episodes = []
+        for seed in (1200, 1201, 1202):
+            env = CollectiveCrossingEnv(config=cs.build_config(configs, reward_configs, terminated_configs,
+                                                               truncated_configs, mix))
+            obs, _ = env.reset(seed=seed)
+            ids = list(env._agents)
+            # two agents start one or two cells from their destination row and walk straight to it, so
+            # that arrivals (and the reward of the finishing step) happen inside the recording
+            forced = {"exiting_0": [3, 1 + seed % 2], "boarding_0": [8, 7 - seed % 2]}
+            for a, pos in forced.items():
+                env._agents[a].position = np.array(pos)
+            rng = np.random.default_rng(seed)
+            steps = []
+            for k in range(24):
+                acting = [a for a in ids if rng.random() > 0.1]
+                rng.shuffle(acting)
+                acts = {a: int(rng.integers(0, 5)) for a in acting}
+                if k < 3:
+                    acts.update({a: v for a, v in (("exiting_0", 3), ("boarding_0", 1)) if a in acts})
+                o, r, te, tr, inf = env.step(dict(acts))
+                steps.append(dict(
+                    actions=acts, observations={k: np.asarray(v, np.float32).tolist() for k, v in sorted(o.items())},
+                    rewards={k: float(v) for k, v in r.items()}, terminateds={k: bool(v) for k, v in te.items()},
+                    truncateds={k: bool(v) for k, v in tr.items()},
+                    infos={k: {kk: (vv if isinstance(vv, str) else bool(vv)) for kk, vv in v.items()} for k, v in inf.items()},
+                    agents=list(env.agents), step_count=int(env._step_count),
+                    flags={a: [bool(env._agents[a].active), bool(env._agents[a].terminated), bool(env._agents[a].truncated)]
+                           for a in ids}))
+            episodes.append(dict(seed=seed, forced=forced, initial={k: np.asarray(v, np.float32).tolist() for k, v in obs.items()}, steps=steps))
+        out[mix_name] = episodes
+    import gzip
+    f = HERE / "g12_custom_strategies.json.gz"
+    with gzip.GzipFile(f, "wb", mtime=0) as z:
+        z.write(json.dumps(out).encode())
+    print(f"wrote {f.name}: {len(out)} strategy mixes x 3 episodes x 24 steps, {f.stat().st_size / 1024:.0f} KiB")
+
+
 ONLY = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
 
 
@@ -438,6 +489,8 @@ def main() -> int:
     run_random, run_greedy, run_scenarios, run_rollout = (_selected(f) for f in (
         run_random, run_greedy, run_scenarios, run_rollout))
 
+    if not ONLY or any("g12_custom_strategies".startswith(p) for p in ONLY):
+        run_custom_strategies()
     # G1 / G2: BASELINE config-1 geometry, random actions, identity and shuffled move order
     run_random("g1_c1_random", cfg_c1(), seeds=range(0, 24), K=110)
     run_random("g2_c1_shuffled_absent", cfg_c1(), seeds=range(100, 116), K=110, shuffle=True,
