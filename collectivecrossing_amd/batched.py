@@ -72,6 +72,7 @@ class BatchedCollectiveCrossing:
             raise ValueError(f"device must be a GPU, got {dev}")
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
         self._stream = torch.cuda.current_stream(self.device)
+        self._stream_raw = self._stream.cuda_stream
         handle = C.c_void_p()
         check(self._lib.ccx_create(C.byref(self.params), self.num_envs, self.env_offset, self.total_envs,
                                    self.device.index, C.c_void_p(self._stream.cuda_stream),
@@ -108,12 +109,14 @@ class BatchedCollectiveCrossing:
 
     def _as_dev_u8(self, a, shape) -> torch.Tensor:
         if isinstance(a, torch.Tensor):
-            t = a.to(device=self.device, dtype=torch.uint8)
+            # (fast path first: a step-wise loop hands over a ready device tensor every few microseconds)
+            t = a if (a.dtype is torch.uint8 and a.device == self.device) else a.to(device=self.device, dtype=torch.uint8)
         else:
             t = torch.from_numpy(np.ascontiguousarray(a, np.uint8)).to(self.device)
         if tuple(t.shape) != tuple(shape):
             raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
-        t = t.contiguous()
+        if not t.is_contiguous():
+            t = t.contiguous()
         self._order_after_current_stream(t)
         return t
 
@@ -123,9 +126,9 @@ class BatchedCollectiveCrossing:
         wait for it and tell the caching allocator that the launch stream uses the buffers (otherwise
         nothing orders the H2D copy before the kernel, and a temporary could be recycled while the
         kernel still reads it)."""
-        cur = torch.cuda.current_stream(self.device)
-        if cur.cuda_stream != self._stream.cuda_stream:
-            self._stream.wait_stream(cur)
+        raw = torch._C._cuda_getCurrentRawStream(self.device.index)      # (an int; ~0.2 us, this is the per-step path)
+        if raw != self._stream_raw:
+            self._stream.wait_stream(torch.cuda.current_stream(self.device))
             for t in tensors:
                 if t is not None and t.is_cuda:
                     t.record_stream(self._stream)
@@ -400,6 +403,13 @@ class BatchedCollectiveCrossing:
         check(self._lib.ccx_get_step_pace(self._h, C.byref(ns)))
         return float(ns.value)
 
+    def pace_state(self) -> dict[str, float]:
+        """The pace controller's state (``ccx_get_pace_state``): next pace / floor in ns, launches since the
+        last collapse, whether rollouts of this shape are paced at all."""
+        v = (C.c_float * 4)()
+        check(self._lib.ccx_get_pace_state(self._h, v))
+        return dict(zip(("next_pace_ns", "floor_ns", "calm_launches", "paced"), (float(x) for x in v)))
+
     def launch_shape(self) -> dict[str, int]:
         v = [C.c_int32() for _ in range(4)]
         check(self._lib.ccx_get_launch_shape(self._h, *[C.byref(x) for x in v]))
@@ -414,7 +424,8 @@ class BatchedCollectiveCrossing:
     def use_stream(self, stream: "torch.cuda.Stream | None" = None) -> None:
         """Launch on ``stream`` (default: torch's current stream of the device) from now on."""
         self._stream = stream if stream is not None else torch.cuda.current_stream(self.device)
-        check(self._lib.ccx_set_stream(self._h, C.c_void_p(self._stream.cuda_stream)))
+        self._stream_raw = self._stream.cuda_stream
+        check(self._lib.ccx_set_stream(self._h, C.c_void_p(self._stream_raw)))
 
     def synchronize(self) -> None:
         check(self._lib.ccx_synchronize(self._h))

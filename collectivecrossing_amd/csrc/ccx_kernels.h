@@ -31,7 +31,7 @@ struct KParams {
     uint32_t writer_vmcnt;               // >0: a writer starts a step only with <= this many of its stores in flight
     // step pacing (rollouts that write observations): every tile starts env-step s no earlier than
     // t0 + s * pace on the 100 MHz s_memrealtime clock; pace = *pace_state in ticks x 256 (0 = off)
-    uint32_t* pace_state;                // [pace_slot] is read, [pace_slot ^ 1] collects the votes, [2] = floor
+    uint32_t* pace_state;                // [pace_slot] is read, [pace_slot ^ 1] collects the votes, [2] = floor, [3] launches since the last collapse
     uint32_t pace_min_fp, pace_max_fp;
     uint32_t pace_slot;
     uint32_t resident_blocks;            // workgroups the device holds at once (0 = unknown)
@@ -44,7 +44,7 @@ struct KParams {
     long long pool_stride;               // cursor stride: total_envs mod pool_size, 1 when that is 0
     // tunables (ccx_set_tunable): how the tiles' step schedules are phased, how workgroups map to tiles,
     // pause between a writer's store iterations
-    uint32_t pace_phase, tile_map, writer_gap;
+    uint32_t pace_phase, tile_map, writer_gap, writer_split;
 };
 
 struct KState {

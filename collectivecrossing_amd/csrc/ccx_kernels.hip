@@ -277,12 +277,15 @@ constexpr int kObsBatch = 5;       // LDS reads issued back to back before their
 #define CCX_T(q) do { } while (0)
 #endif
 
-template <int GLOG, bool PAIR, bool OUT, bool OCC>
+//   PLAIN  the caller passed neither a move order nor a policy (the bench line, plain RL stepping): the step
+//        loop is compiled without those branches (12 % fewer cycles per env-step on the sim chain).
+template <int GLOG, bool PAIR, bool OUT, bool OCC, bool PLAIN>
 __global__ void __launch_bounds__(512)
 rollout_kernel(const KParams p, const KState st, const unsigned long long* __restrict__ cell_info,
                const uint8_t* __restrict__ actions, const uint8_t* __restrict__ order, const int K,
                const int auto_reset, const uint8_t* __restrict__ pool, const KOut out,
-               unsigned long long* counters, const int policy, uint8_t* __restrict__ actions_out) {
+               unsigned long long* counters, const int policy_arg, uint8_t* __restrict__ actions_out) {
+    const int policy = PLAIN ? 0 : policy_arg;
     using mask_t = typename GroupMask<GLOG>::type;
     constexpr int G = 1 << GLOG;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -298,10 +301,18 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     // writes one contiguous eighth of every step's output slab instead of every eighth chunk --
     // the pace at which the output stream collapses moves from ~740 to ~700 ns per env-step on C2
     // (profiles/scratch/tile_times.py).
-    int bid = blockIdx.x;     // tunable tile_map = 1: the plain blockIdx -> tile mapping
-    if (!p.tile_map) {
+    // tile_map: 0 = XCD-contiguous (above); v >= 1 = groups of 2^(v-1) adjacent tiles per XCD, dealt
+    // round-robin (1 = the plain blockIdx -> tile mapping): with the tiles phased in tile order
+    // (pace_phase 1) the chip writes ONE window that sweeps through the slab, fed by all eight XCDs,
+    // while the small partial-line outputs of a group still meet in one L2.
+    int bid = blockIdx.x;
+    if (p.tile_map == 0u) {
         const int nb = gridDim.x, xcd = blockIdx.x & 7, q8 = nb >> 3, r8 = nb & 7;
         bid = xcd * q8 + (xcd < r8 ? xcd : r8) + (int)(blockIdx.x >> 3);
+    } else if (p.tile_map > 1u) {
+        const uint32_t m = p.tile_map - 1u, span = 8u << m, b = blockIdx.x;
+        if (b < (gridDim.x / span) * span)       // (a tail that does not fill a span keeps the plain mapping)
+            bid = (int)((b & ~(span - 1u)) + ((b & 7u) << m) + ((b >> 3) & ((1u << m) - 1u)));
     }
     const int tile = bid * tpb + tile_in_block;
     const int g = lane >> GLOG;
@@ -342,6 +353,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
         const uint32_t w = threadIdx.x + (uint32_t)r * blockDim.x;
         t_first[r] = w < tw ? tsrc[w] : 0u;
     }
+    const bool sim_wave = !OUT || role == 0;
     if constexpr (OCC) {   // zero the occupancy / proposal tables of every tile of the block
         for (int ti = 0; ti < tpb; ++ti) {
             uint32_t* occ = reinterpret_cast<uint32_t*>(smem + p.off_tiles + (uint32_t)ti * p.tile_stride + p.off_occ);
@@ -410,13 +422,11 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             const int n4l = n4 + (int)lead;               // one past the last slot of the shifted layout
             // my store iterations: it0, it0 + it_step, ... below it_end (one iteration = 64 vector units)
             const int total_its = (n4l + 63) >> 6;
-#ifdef CCX_INTERLEAVED_WRITERS   // diagnostic: writer w takes iterations w, w + nw, ... (1-KiB chunks)
-            const int it0 = w, it_step = nw, it_end = total_its;
-#else   // each writer takes one contiguous share of the region (+0.5 % on C3 / C5 under pacing)
+            // each writer takes one contiguous share of the region (+0.5 % on C3 / C5 under pacing); tunable
+            // writer_split = 1: writer w takes iterations w, w + nw, ... (the writers sweep the region together)
             const int per_w = (total_its + nw - 1) / nw;
-            const int it0 = w * per_w, it_step = 1;
-            const int it_end = (it0 + per_w) < total_its ? (it0 + per_w) : total_its;
-#endif
+            const int it0 = p.writer_split ? w : w * per_w, it_step = p.writer_split ? nw : 1;
+            const int it_end = p.writer_split ? total_its : ((it0 + per_w) < total_its ? (it0 + per_w) : total_its);
             // LDS source addresses of this lane's first kFastObsIters observation stores
             uint32_t oa0[kFastObsIters], oa1[kFastObsIters];
 #pragma unroll
@@ -539,15 +549,19 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
     const mask_t full = full_mask<GLOG>();
     const mask_t lo_m = low_mask<mask_t>(i);
     const mask_t later_m = ~lo_m & ~(mask_t(1) << i);
-    // occupancy / proposal bit tables of this lane's env: [cells + 1] masks each, the last entry
-    // is a dump slot for lanes that have nothing to publish
+    // occupancy / proposal bit tables of this lane's env: [cells + 1] masks each, the last entry is a dump
+    // slot for agents that have nothing to publish.  Lanes WITHOUT an agent (half-empty waves of small
+    // batches, padded lane groups) get dump words of their own on the top border row (y = -1, never
+    // occupied): 32+ lanes hammering one dump word with same-address LDS atomics cost such tiles 10 % per
+    // step (4096 x 8 at 2048 envs: 0.61 -> 0.55 us), while steering the few idle agents of an env to its one
+    // dump word is cheaper than letting them OR a zero into their own cells (0.54 vs 0.565 us per step).
     constexpr uint32_t msz = sizeof(mask_t);
     const uint32_t cells1 = cells + 1u;
-    const uint32_t g_tab = (g < p.EW) ? (uint32_t)g : 0u;   // unused lanes share env 0's dump slot
+    const uint32_t g_tab = (g < p.EW) ? (uint32_t)g : 0u;   // lanes beyond the tile's envs use env 0's tables (zeros only)
     const uint32_t occ_base = p.off_tiles + (uint32_t)tile_in_block * p.tile_stride + p.off_occ +
                               g_tab * 2u * cells1 * msz;
     const uint32_t prp_base = occ_base + cells1 * msz;
-    const uint32_t dump_off = cells * msz;
+    const uint32_t dump_off = valid ? cells * msz : (uint32_t)(lane % Wp) * msz;
 
     // ---- state -> registers ------------------------------------------------------------------
     int c = Wp + 1;               // cell index of (0,0)
@@ -598,24 +612,25 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
         pnext_pending = true;
     }
 
-    const uint8_t* act_p = actions + idx;
-    const bool has_order = order != nullptr;   // wave-uniform
+    const bool has_order = PLAIN ? false : order != nullptr;   // wave-uniform
     const uint8_t* ord_p = order + idx;
 
     uint32_t c_moves = 0, c_arrivals = 0, c_live = 0, c_episodes = 0;
     CCX_STAMP_DECL;
 
+    const uint8_t* act_p = actions + idx;
     // ---- actions: bursts of kActBatch steps, 4 bits per step ----------------------------------
-    // One s_waitcnt vmcnt per burst instead of one per step.  Loads are unconditional (steps past
-    // K re-read the last valid step) and addressed from a VGPR stride: straight-line code.
+    // One s_waitcnt vmcnt per burst instead of one per step, addressed from a VGPR stride.
     uint32_t araw[kActBatch];
     const size_t EN_v = in_vgpr(EN);
     auto fetch_actions = [&](int s_first) {
         const int last = K - 1 - s_first;   // >= 0 whenever this is called
 #pragma unroll
         for (int d = 0; d < kActBatch; ++d) {
-            const int dd = d < last ? d : last;
-            araw[d] = valid ? (uint32_t)act_p[(size_t)dd * EN_v] : 4u;
+            // (steps past K are never consumed: no load for them -- a single-step launch issues ONE action
+            // load, not sixteen; the branch is wave-uniform)
+            araw[d] = 4u;
+            if (d <= last && sim_wave && valid) araw[d] = (uint32_t)act_p[(size_t)d * EN_v];
         }
         act_p += (size_t)kActBatch * EN_v;
     };
@@ -663,8 +678,15 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             // lateness test are relative to it.
             const uint32_t per_round = (p.resident_blocks ? p.resident_blocks : gridDim.x) * (uint32_t)tpb;
             const uint32_t tr = (uint32_t)tile % per_round;
-            const uint32_t frac16 = p.pace_phase == 1u ? (tr << 16) / per_round
-                                                       : (__brev(tr * 2654435761u) & 0xFFFFu);
+            uint32_t frac16;
+            if (p.pace_phase == 1u) {
+                frac16 = (tr << 16) / per_round;                       // one window for the whole chip
+            } else if (p.pace_phase == 3u) {
+                const uint32_t per_xcd = per_round >> 3;               // one window per XCD (tile_map 0)
+                frac16 = per_xcd ? ((tr % per_xcd) << 16) / per_xcd : 0u;
+            } else {
+                frac16 = __brev(tr * 2654435761u) & 0xFFFFu;
+            }
             pace_t0 += ((unsigned long long)pace * frac16) >> 24;
         }
     }
@@ -1106,7 +1128,7 @@ __global__ void reset_from_pool_kernel(const KParams p, const KState st,
 // ---------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------
-template <int GLOG, bool PAIR, bool OUT, bool OCC>
+template <int GLOG, bool PAIR, bool OUT, bool OCC, bool PLAIN>
 static hipError_t launch_rollout_v(const LaunchShape& ls, hipStream_t stream, const KParams& p,
                                    const KState& st, const unsigned long long* cell_info,
                                    const uint8_t* actions, const uint8_t* order, int K,
@@ -1114,12 +1136,12 @@ static hipError_t launch_rollout_v(const LaunchShape& ls, hipStream_t stream, co
                                    unsigned long long* counters, int policy, uint8_t* actions_out) {
     if (ls.lds_bytes > 60 * 1024) {
         // big grids / many envs per tile need more than the default 64 KiB of dynamic LDS
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<GLOG, PAIR, OUT, OCC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<GLOG, PAIR, OUT, OCC, PLAIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
     dim3 grid(ls.num_blocks), block(64 * ls.waves_per_block * (OUT ? 1 + ls.writers : 1));
-    hipLaunchKernelGGL((rollout_kernel<GLOG, PAIR, OUT, OCC>), grid, block, ls.lds_bytes, stream, p, st,
+    hipLaunchKernelGGL((rollout_kernel<GLOG, PAIR, OUT, OCC, PLAIN>), grid, block, ls.lds_bytes, stream, p, st,
                        cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
     return hipGetLastError();
 }
@@ -1133,9 +1155,12 @@ static hipError_t launch_rollout_g(const LaunchShape& ls, hipStream_t stream, co
     const bool pair = (p.N % 2) == 0;
     const bool want_out = out.obs || out.reward || out.agent_flags || out.env_flags || actions_out;
     const int sel = (pair ? 4 : 0) | (want_out ? 2 : 0) | (ls.occ ? 1 : 0);
-#define CCX_GO(P_, O_, C_)                                                                       \
-    return launch_rollout_v<GLOG, P_, O_, C_>(ls, stream, p, st, cell_info, actions, order, K,  \
-                                              auto_reset, pool, out, counters, policy, actions_out)
+    const bool plain = order == nullptr && policy == 0;
+#define CCX_GO(P_, O_, C_)                                                                                   \
+    return plain ? launch_rollout_v<GLOG, P_, O_, C_, true>(ls, stream, p, st, cell_info, actions, order, K, \
+                                                            auto_reset, pool, out, counters, policy, actions_out) \
+                 : launch_rollout_v<GLOG, P_, O_, C_, false>(ls, stream, p, st, cell_info, actions, order, K, \
+                                                             auto_reset, pool, out, counters, policy, actions_out)
     switch (sel) {
     case 7: CCX_GO(true, true, true);
     case 6: CCX_GO(true, true, false);
@@ -1156,7 +1181,7 @@ static int blocks_per_cu_g(const LaunchShape& ls, bool pair) {
     hipError_t e = hipSuccess;
 #define CCX_OCCQ(P_, C_)                                                                          \
     do {                                                                                          \
-        const void* f = reinterpret_cast<const void*>(&rollout_kernel<GLOG, P_, true, C_>);       \
+        const void* f = reinterpret_cast<const void*>(&rollout_kernel<GLOG, P_, true, C_, true>);       \
         if (ls.lds_bytes > 60 * 1024)                                                             \
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, threads, ls.lds_bytes);           \

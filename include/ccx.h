@@ -308,15 +308,24 @@ int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight);
  * ccx_get_step_pace returns the pace in effect (synchronises).  Results never depend on it. */
 int ccx_set_step_pace(ccx_handle* h, int32_t ns_per_env_step);
 int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step);
+/* The controller's state for diagnostics and tests (synchronises): out4 = { the pace the next launch starts
+ * from (ns), the floor just above the last collapse (ns), launches since that collapse, 1 if rollouts of this
+ * shape are paced at all } */
+int ccx_get_pace_state(ccx_handle* h, float* out4);
 /* Where the ADAPTIVE controller starts (ns per env-step; 0 = the library's assumption of 6.8 TB/s): a
  * caller that remembers the pace a previous handle of the same shape converged to (ccx_get_step_pace)
  * skips the descent of the first launches.  Restarts the controller. */
 int ccx_set_step_pace_start(ccx_handle* h, float ns_per_env_step);
-/* Performance experiments without an ABI change; results never depend on a tunable.
- *   "pace_phase"  0 = every tile starts env-step s at t0 + s * pace (default), 1 = tiles are phased over
- *                 the step period in tile order, 2 = hashed phases
- *   "tile_map"    0 = workgroups of one XCD take adjacent tiles (default), 1 = tile = workgroup index
- *   "writer_gap"  pause (x ~128 clocks) after each batch of a writer's observation stores, 0..64 */
+/* Performance experiments without an ABI change; results never depend on a tunable.  -1 = the library's
+ * choice for the launch shape (pace_phase, tile_map).
+ *   "pace_phase"   0 = every tile starts env-step s at t0 + s * pace, 1 = tiles are phased over the step
+ *                  period in tile order (one write window sweeps through the slab), 2 = hashed phases,
+ *                  3 = in tile order within each XCD's share (with tile_map 0)
+ *   "tile_map"     0 = workgroups of one XCD take adjacent tiles, v >= 1 = groups of 2^(v-1) adjacent tiles
+ *                  per XCD dealt round-robin (1 = tile = workgroup index)
+ *   "writer_split" 0 = each writer wave takes one contiguous share of a tile's observation region,
+ *                  1 = the writers of a tile interleave 1-KiB store iterations
+ *   "writer_gap"   pause (x ~128 clocks) after each batch of a writer's observation stores, 0..64 */
 int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value);
 /* workgroups of a rollout launch with outputs, and how many of them the device holds at once (a grid
  * larger than that runs in rounds; the pace of a partial last round is scaled accordingly) */

@@ -79,8 +79,9 @@ def test_full_size_c3_shuffled_orders_equal_the_oracle(oracle, ccx):
     _against_oracle(oracle, ccx, g, E=4096, K=6, seed=32, order=True)
 
 
-@pytest.mark.parametrize("knobs", [{"pace_phase": 1}, {"pace_phase": 2}, {"tile_map": 1},
-                                   {"pace_phase": 1, "tile_map": 1, "writer_gap": 3}])
+@pytest.mark.parametrize("knobs", [{"pace_phase": 0, "tile_map": 0}, {"pace_phase": 1, "tile_map": 1}, {"pace_phase": 2, "tile_map": 4},
+                                   {"pace_phase": 3, "tile_map": 0, "writer_split": 1},
+                                   {"pace_phase": 1, "tile_map": 6, "writer_gap": 3}])
 @pytest.mark.parametrize("cfg_name,E,K", [("g1_c1_random", 4096, 70), ("g3_c3_dense_simple_distance", 1500, 20)])
 def test_tunables_never_change_results(oracle, ccx, cfg_name, E, K, knobs):
     def setup(env):
@@ -94,7 +95,7 @@ def test_unknown_tunable_is_rejected(ccx):
     env = ccx(Golden("g7_n3_small").config, 4)
     with pytest.raises(CcxError, match="unknown tunable"):
         env.set_tunable("warp_speed", 1)
-    with pytest.raises(CcxError, match="must be 0..2"):
+    with pytest.raises(CcxError, match="must be -1..3"):
         env.set_tunable("pace_phase", 9)
     env.close()
 
