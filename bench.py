@@ -298,6 +298,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the no-obs / K=1 secondary figures")
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip the observation output")
+    ap.add_argument("--compact-obs", action="store_true",
+                    help="diagnostic: CCX_OBS_COMPACT [E][N][4] rows instead of the DefaultObservation rows "
+                         "(never the bench line: 16 B instead of 16N+24 B of observation per agent-step)")
     ap.add_argument("--only-obs", action="store_true", help="diagnostic: skip reward / flag outputs")
     ap.add_argument("--direct-rccl", action="store_true",
                     help="reduce the counters with ccx_rccl_allreduce_counters (RCCL through the C-ABI) instead of "
@@ -387,8 +390,10 @@ def run_rank(args) -> int:
     # the action stream holds `n_buf` launches worth of steps and wraps around
     n_buf = max(1, min(max(args.steps, args.warmup, 1), 8))
     actions = torch.randint(0, 5, (n_buf * chunk, E, N), dtype=torch.uint8, device=dev, generator=gen)
-    traj = env.alloc_rollout(chunk, want_obs=not args.no_obs)
-    view = traj if not args.only_obs else type(traj)(traj.obs, None, None, None)
+    if args.compact_obs:
+        args.no_obs = True
+    traj = env.alloc_rollout(chunk, want_obs=not args.no_obs, want_compact=args.compact_obs)
+    view = traj if not args.only_obs else type(traj)(traj.obs, None, None, None, traj.obs_compact)
     launched = 0
 
     def run(nlaunches, events=None):
@@ -426,7 +431,7 @@ def run_rank(args) -> int:
         return elapsed, mine, [a.elapsed_time(b) for a, b in events], counters
 
     direct = sharding.RcclCounterReducer(env, rank, world) if args.direct_rccl else None
-    bytes_unit = rollout_bytes_per_agent_step(N) - (4 * L if args.no_obs else 0)
+    bytes_unit = rollout_bytes_per_agent_step(N) - (4 * L if args.no_obs else 0) + (16 if args.compact_obs else 0)
     launch_bytes = bytes_unit * chunk * E * N
 
     def summarize(elapsed, launch_ms):
@@ -491,7 +496,8 @@ def run_rank(args) -> int:
                        "ms_per_env_step": elapsed * 1e3 / (args.steps * chunk),
                        "settle_launches": settle,
                        "launch_shape": env.launch_shape(), "step_pace_ns": env.step_pace_ns(),
-                       "outputs": "full trajectory" + (" (no obs)" if args.no_obs else "")},
+                       "outputs": "full trajectory" + (" (compact obs [E][N][4] instead of the rows)" if args.compact_obs
+                                                       else " (no obs)" if args.no_obs else "")},
             "counters": counters,
             "device": {"name": props.name, "compute_units": props.multi_processor_count,
                        "hbm_GiB": round(props.total_memory / 2**30, 1)},

@@ -58,12 +58,12 @@ class CcxState(C.Structure):
 
 class CcxStepOut(C.Structure):
     _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("agent_flags", C.c_void_p),
-                ("env_flags", C.c_void_p)]
+                ("env_flags", C.c_void_p), ("obs_compact", C.c_void_p)]
 
 
 class CcxRolloutOut(C.Structure):
     _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("agent_flags", C.c_void_p),
-                ("env_flags", C.c_void_p)]
+                ("env_flags", C.c_void_p), ("obs_compact", C.c_void_p)]
 
 
 class CcxCounters(C.Structure):
@@ -100,6 +100,7 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_greedy_actions": (C.c_int, [_H, C.c_void_p]),
     "ccx_policy_actions": (C.c_int, [_H, C.c_int32, C.c_void_p]),
     "ccx_observe": (C.c_int, [_H, C.c_void_p]),
+    "ccx_expand_observations": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p]),
     "ccx_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.POINTER(CcxStepOut)]),
     "ccx_rollout": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                               C.POINTER(CcxRolloutOut)]),

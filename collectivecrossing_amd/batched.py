@@ -36,6 +36,7 @@ class StepResult:
     reward: torch.Tensor      # f64 [E, N]
     agent_flags: torch.Tensor  # u8 [E, N]  (_abi.AF_*)
     env_flags: torch.Tensor   # u8 [E]     (_abi.EF_*)
+    obs_compact: torch.Tensor | None = None   # f32 [E, N, 4]  (x, y, type, active), CCX_OBS_COMPACT
 
 
 @dataclass
@@ -44,6 +45,7 @@ class RolloutResult:
     reward: torch.Tensor | None  # f64 [K, E, N]
     agent_flags: torch.Tensor | None  # u8 [K, E, N]
     env_flags: torch.Tensor | None    # u8 [K, E]
+    obs_compact: torch.Tensor | None = None   # f32 [K, E, N, 4], CCX_OBS_COMPACT
 
 
 def _ptr(t: torch.Tensor | None) -> C.c_void_p:
@@ -240,7 +242,7 @@ class BatchedCollectiveCrossing:
         check(self._lib.ccx_observe(self._h, _ptr(out)))
         return out
 
-    def step(self, actions, order=None, want_obs: bool = True) -> StepResult:
+    def step(self, actions, order=None, want_obs: bool = True, want_compact: bool = False) -> StepResult:
         E, N = self.num_envs, self.num_agents
         a = self._as_dev_u8(actions, (E, N))
         o = None if order is None else self._as_dev_u8(order, (E, N))
@@ -249,30 +251,48 @@ class BatchedCollectiveCrossing:
                                          self._new((E, N), torch.float64),
                                          self._new((E, N), torch.uint8), self._new((E,), torch.uint8))
         b = self._step_bufs
+        if want_compact and b.obs_compact is None:
+            b.obs_compact = self._new((E, N, 4), torch.float32)
         so = _abi.CcxStepOut(_ptr(b.obs if want_obs else None).value, _ptr(b.reward).value,
-                             _ptr(b.agent_flags).value, _ptr(b.env_flags).value)
+                             _ptr(b.agent_flags).value, _ptr(b.env_flags).value,
+                             _ptr(b.obs_compact if want_compact else None).value)
         check(self._lib.ccx_step(self._h, _ptr(a), _ptr(o), C.byref(so)))
-        return StepResult(b.obs if want_obs else None, b.reward, b.agent_flags, b.env_flags)
+        return StepResult(b.obs if want_obs else None, b.reward, b.agent_flags, b.env_flags,
+                          b.obs_compact if want_compact else None)
 
-    def alloc_rollout(self, num_steps: int, want_obs: bool = True) -> RolloutResult:
+    def alloc_rollout(self, num_steps: int, want_obs: bool = True, want_compact: bool = False) -> RolloutResult:
         K, E, N = num_steps, self.num_envs, self.num_agents
         return RolloutResult(self._new((K, E, N, self.obs_len), torch.float32) if want_obs else None,
                              self._new((K, E, N), torch.float64), self._new((K, E, N), torch.uint8),
-                             self._new((K, E), torch.uint8))
+                             self._new((K, E), torch.uint8),
+                             self._new((K, E, N, 4), torch.float32) if want_compact else None)
+
+    def expand_observations(self, obs_compact: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Compact rows ``[..., N, 4]`` -> DefaultObservation rows ``[..., N, L]`` on the device
+        (``ccx_expand_observations``: the gather of ``ccx_observe``, bit for bit; observations.py:43-94)."""
+        c = obs_compact.to(device=self.device, dtype=torch.float32).contiguous()
+        if c.shape[-2:] != (self.num_agents, 4):
+            raise ValueError(f"expected [..., {self.num_agents}, 4], got {tuple(c.shape)}")
+        rows = int(c.numel() // (self.num_agents * 4))
+        if out is None:
+            out = self._new((*c.shape[:-1], self.obs_len), torch.float32)
+        self._order_after_current_stream(c, out)
+        check(self._lib.ccx_expand_observations(self._h, _ptr(c), rows, _ptr(out)))
+        return out
 
     def rollout(self, actions, order=None, auto_reset: bool = False,
                 out: RolloutResult | None = None, want_obs: bool = True,
-                want_traj: bool = True) -> RolloutResult | None:
+                want_traj: bool = True, want_compact: bool = False) -> RolloutResult | None:
         """K fused steps (``ccx_rollout``); ``actions`` u8 [K, E, N] on the device."""
         K = int(actions.shape[0])
         E, N = self.num_envs, self.num_agents
         a = self._as_dev_u8(actions, (K, E, N))
         o = None if order is None else self._as_dev_u8(order, (K, E, N))
         if out is None and want_traj:
-            out = self.alloc_rollout(K, want_obs)
+            out = self.alloc_rollout(K, want_obs, want_compact)
         if out is not None:
             ro = _abi.CcxRolloutOut(_ptr(out.obs).value, _ptr(out.reward).value,
-                                    _ptr(out.agent_flags).value, _ptr(out.env_flags).value)
+                                    _ptr(out.agent_flags).value, _ptr(out.env_flags).value, _ptr(out.obs_compact).value)
             check(self._lib.ccx_rollout(self._h, K, _ptr(a), _ptr(o), int(bool(auto_reset)), C.byref(ro)))
             self._rollouts_with_obs += int(out.obs is not None and K >= 64)
         else:
@@ -290,7 +310,7 @@ class BatchedCollectiveCrossing:
         if actions_out is None and want_actions:
             actions_out = self._new((K, E, N), torch.uint8)
         ro = _abi.CcxRolloutOut(_ptr(out.obs).value, _ptr(out.reward).value,
-                                _ptr(out.agent_flags).value, _ptr(out.env_flags).value)
+                                _ptr(out.agent_flags).value, _ptr(out.env_flags).value, _ptr(out.obs_compact).value)
         check(self._lib.ccx_rollout_policy(self._h, K, _abi.POLICIES[policy], int(bool(auto_reset)),
                                            C.byref(ro), _ptr(actions_out)))
         self._rollouts_with_obs += int(out.obs is not None and K >= 64)

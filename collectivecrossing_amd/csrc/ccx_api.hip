@@ -281,6 +281,8 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
         return fail(CCX_EINVAL, "obs buffer must be 16-byte aligned");
     if (out.reward && (reinterpret_cast<uintptr_t>(out.reward) & 7u))
         return fail(CCX_EINVAL, "reward buffer must be 8-byte aligned");
+    if (out.obs_compact && (reinterpret_cast<uintptr_t>(out.obs_compact) & 15u))
+        return fail(CCX_EINVAL, "obs_compact buffer must be 16-byte aligned");
     CCX_HIP(hipSetDevice(h->device));
     if (h->pace_dirty) {   // (re)start the pace controller: new handle, new launch shape or new setting
         CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state), 0, 4, h->stream));   // floor = 0
@@ -576,6 +578,17 @@ int ccx_observe(ccx_handle* h, float* obs) {
     return CCX_OK;
 }
 
+int ccx_expand_observations(ccx_handle* h, const float* obs_compact, int64_t rows, float* obs) {
+    if (!h || !obs_compact || !obs) return fail(CCX_EINVAL, "NULL argument");
+    if (rows < 0 || rows * (int64_t)h->N >= (1ll << 31)) return fail(CCX_EINVAL, "rows = %lld out of range", (long long)rows);
+    if ((reinterpret_cast<uintptr_t>(obs) | reinterpret_cast<uintptr_t>(obs_compact)) & 15u)
+        return fail(CCX_EINVAL, "obs and obs_compact must be 16-byte aligned");
+    CCX_HIP(hipSetDevice(h->device));
+    hipError_t e = ccx::launch_expand(h->shape, h->stream, h->kp, obs_compact, rows, obs);
+    if (e != hipSuccess) return fail(CCX_EHIP, "expand kernel launch failed: %s", hipGetErrorString(e));
+    return CCX_OK;
+}
+
 int ccx_step(ccx_handle* h, const uint8_t* actions, const uint8_t* order, const ccx_step_out* out) {
     if (!h || !actions) return fail(CCX_EINVAL, "NULL argument");
     ccx::KOut ko{};
@@ -584,6 +597,7 @@ int ccx_step(ccx_handle* h, const uint8_t* actions, const uint8_t* order, const 
         ko.reward = out->reward;
         ko.agent_flags = out->agent_flags;
         ko.env_flags = out->env_flags;
+        ko.obs_compact = out->obs_compact;
     }
     return run_rollout(h, 1, actions, order, 0, ko);
 }
@@ -600,6 +614,7 @@ int ccx_rollout(ccx_handle* h, int32_t num_steps, const uint8_t* actions, const 
         ko.reward = out->reward;
         ko.agent_flags = out->agent_flags;
         ko.env_flags = out->env_flags;
+        ko.obs_compact = out->obs_compact;
     }
     return run_rollout(h, num_steps, actions, order, auto_reset ? 1 : 0, ko);
 }
@@ -620,6 +635,7 @@ int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t
         ko.reward = out->reward;
         ko.agent_flags = out->agent_flags;
         ko.env_flags = out->env_flags;
+        ko.obs_compact = out->obs_compact;
     }
     return run_rollout(h, num_steps, nullptr, nullptr, auto_reset ? 1 : 0, ko, policy, actions_out);
 }

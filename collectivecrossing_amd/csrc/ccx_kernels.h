@@ -62,6 +62,7 @@ struct KOut {
     double* reward;
     uint8_t* agent_flags;
     uint8_t* env_flags;
+    float* obs_compact;   // [..][E][N][4]: (x, y, type, active) of every agent slot, once per env and step
 };
 
 // LDS tile a writer wave gathers observation rows from: float4 (x, y, type, active) per lane, then
@@ -111,6 +112,9 @@ int rollout_blocks_per_cu(const LaunchShape& ls, int agents);
 hipError_t launch_reduce_counters(hipStream_t stream, unsigned long long* counters, int slots);
 hipError_t launch_observe(const LaunchShape& ls, hipStream_t stream, const KParams& p,
                           const KState& st, float* obs);
+// DefaultObservation rows [rows][N][L] from compact rows [rows][N][4] (rows = envs x steps)
+hipError_t launch_expand(const LaunchShape& ls, hipStream_t stream, const KParams& p, const float* compact,
+                         long long rows, float* obs);
 hipError_t launch_reset_from_pool(hipStream_t stream, const KParams& p, const KState& st,
                                   const uint8_t* env_mask, const uint8_t* pool);
 

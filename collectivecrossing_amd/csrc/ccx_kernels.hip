@@ -406,6 +406,10 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             char* af_s = small_out ? reinterpret_cast<char*>(out.agent_flags) : nullptr;
             char* ef_s = small_out ? reinterpret_cast<char*>(out.env_flags) : nullptr;
             char* act_s = small_out ? reinterpret_cast<char*>(actions_out) : nullptr;   // policy rollouts
+            // compact observation: the (x, y, type, active) of this lane's agent, 16 bytes per agent-step
+            // instead of the 16N + 24 of the DefaultObservation rows that repeat it N times
+            char* cmp_s = small_out ? reinterpret_cast<char*>(out.obs_compact) : nullptr;
+            const uint32_t cmp_off = (uint32_t)idx * 16u;
             char* obs_s = reinterpret_cast<char*>(out.obs) + (size_t)env0 * N * L * 4;
             const size_t obs_stride = EN * (size_t)L * 4;
             // Store iterations are laid out on 128-byte lines of GLOBAL memory, not from the start of
@@ -453,10 +457,15 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                 const uint4 e = stage[(s & 1) * 64 + lane];
                 CCX_STAMP(0);                        // wait for the sim wave
                 const uint32_t ilo = e.x, ihi = e.y, af = e.z;
-                if (want_obs) {
+                if (want_obs || cmp_s) {
                     // (x, y) are bytes 2 and 3 of the cell word: v_cvt_f32_ubyte2 / ubyte3
-                    wl->slot[lane] = make_float4((float)((ilo >> 16) & 0xFFu), (float)(ilo >> 24), type_f,
-                                                 (float)((af >> 6) & 1u));
+                    const float4 me = make_float4((float)((ilo >> 16) & 0xFFu), (float)(ilo >> 24), type_f,
+                                                  (float)((af >> 6) & 1u));
+                    if (want_obs) wl->slot[lane] = me;
+                    if (cmp_s) {
+                        if (valid) *reinterpret_cast<float4*>(cmp_s + cmp_off) = me;
+                        cmp_s += EN * 16;
+                    }
                 }
                 if (small_out) {
                     // rewards.py:44-182.  Distances are integers and the reference negates the
@@ -1070,9 +1079,11 @@ hipError_t launch_reduce_counters(hipStream_t stream, unsigned long long* counte
 }
 
 // DefaultObservation of the current state (what reset() returns, collectivecrossing.py:153-159)
+// compact != nullptr: the rows come from compact observations [E][N][4] (the inverse of CCX_OBS_COMPACT: E =
+// envs x steps) instead of the handle's state -- the same gather, hence the same bits.
 template <int GLOG, bool PAIR>
 __global__ void __launch_bounds__(256)
-observe_kernel(const KParams p, const KState st, float* __restrict__ obs) {
+observe_kernel(const KParams p, const KState st, float* __restrict__ obs, const float4* __restrict__ compact) {
     constexpr int G = 1 << GLOG;
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -1086,15 +1097,18 @@ observe_kernel(const KParams p, const KState st, float* __restrict__ obs) {
     uint16_t* table = reinterpret_cast<uint16_t*>(smem + sizeof(WaveLds) * p.waves_per_block);
     build_obs_table<GLOG>(table, p);
     init_wave_consts(wl, p, lane);
-    int x = 0, y = 0;
-    bool active = false;
+    float4 me = make_float4(0.0f, 0.0f, (i < p.Nb) ? 0.0f : 1.0f, 0.0f);
     if (valid) {
         const size_t idx = (size_t)env * N + i;
-        x = st.x[idx];
-        y = st.y[idx];
-        active = st.active[idx] != 0;
+        if (compact) {
+            me = compact[idx];
+        } else {
+            me.x = (float)st.x[idx];
+            me.y = (float)st.y[idx];
+            me.w = st.active[idx] != 0 ? 1.0f : 0.0f;
+        }
     }
-    wl->slot[lane] = make_float4((float)x, (float)y, (i < p.Nb) ? 0.0f : 1.0f, active ? 1.0f : 0.0f);
+    wl->slot[lane] = me;
     __syncthreads();
     int envs_here = p.E - env0;
     envs_here = envs_here < 0 ? 0 : (envs_here > p.EW ? p.EW : envs_here);
@@ -1153,7 +1167,7 @@ static hipError_t launch_rollout_g(const LaunchShape& ls, hipStream_t stream, co
                                    int auto_reset, const uint8_t* pool, const KOut& out,
                                    unsigned long long* counters, int policy, uint8_t* actions_out) {
     const bool pair = (p.N % 2) == 0;
-    const bool want_out = out.obs || out.reward || out.agent_flags || out.env_flags || actions_out;
+    const bool want_out = out.obs || out.reward || out.agent_flags || out.env_flags || out.obs_compact || actions_out;
     const int sel = (pair ? 4 : 0) | (want_out ? 2 : 0) | (ls.occ ? 1 : 0);
     const bool plain = order == nullptr && policy == 0;
 #define CCX_GO(P_, O_, C_)                                                                                   \
@@ -1211,13 +1225,13 @@ int rollout_blocks_per_cu(const LaunchShape& ls, int agents) {
 
 template <int GLOG>
 static hipError_t launch_observe_g(const LaunchShape& ls, hipStream_t stream, const KParams& p,
-                                   const KState& st, float* obs) {
+                                   const KState& st, float* obs, const float4* compact, unsigned blocks) {
     const bool pair = (p.N % 2) == 0;
-    dim3 grid(ls.num_blocks), block(64 * ls.waves_per_block);
+    dim3 grid(blocks), block(64 * ls.waves_per_block);
     if (pair)
-        hipLaunchKernelGGL((observe_kernel<GLOG, true>), grid, block, ls.lds_bytes_observe, stream, p, st, obs);
+        hipLaunchKernelGGL((observe_kernel<GLOG, true>), grid, block, ls.lds_bytes_observe, stream, p, st, obs, compact);
     else
-        hipLaunchKernelGGL((observe_kernel<GLOG, false>), grid, block, ls.lds_bytes_observe, stream, p, st, obs);
+        hipLaunchKernelGGL((observe_kernel<GLOG, false>), grid, block, ls.lds_bytes_observe, stream, p, st, obs, compact);
     return hipGetLastError();
 }
 
@@ -1238,18 +1252,34 @@ hipError_t launch_rollout(const LaunchShape& ls, hipStream_t stream, const KPara
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_observe(const LaunchShape& ls, hipStream_t stream, const KParams& p,
-                          const KState& st, float* obs) {
+static hipError_t launch_observe_any(const LaunchShape& ls, hipStream_t stream, const KParams& p, const KState& st,
+                                     float* obs, const float4* compact, unsigned blocks) {
     switch (ls.glog) {
-    case 0: return launch_observe_g<0>(ls, stream, p, st, obs);
-    case 1: return launch_observe_g<1>(ls, stream, p, st, obs);
-    case 2: return launch_observe_g<2>(ls, stream, p, st, obs);
-    case 3: return launch_observe_g<3>(ls, stream, p, st, obs);
-    case 4: return launch_observe_g<4>(ls, stream, p, st, obs);
-    case 5: return launch_observe_g<5>(ls, stream, p, st, obs);
-    case 6: return launch_observe_g<6>(ls, stream, p, st, obs);
+    case 0: return launch_observe_g<0>(ls, stream, p, st, obs, compact, blocks);
+    case 1: return launch_observe_g<1>(ls, stream, p, st, obs, compact, blocks);
+    case 2: return launch_observe_g<2>(ls, stream, p, st, obs, compact, blocks);
+    case 3: return launch_observe_g<3>(ls, stream, p, st, obs, compact, blocks);
+    case 4: return launch_observe_g<4>(ls, stream, p, st, obs, compact, blocks);
+    case 5: return launch_observe_g<5>(ls, stream, p, st, obs, compact, blocks);
+    case 6: return launch_observe_g<6>(ls, stream, p, st, obs, compact, blocks);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_observe(const LaunchShape& ls, hipStream_t stream, const KParams& p,
+                          const KState& st, float* obs) {
+    return launch_observe_any(ls, stream, p, st, obs, nullptr, (unsigned)ls.num_blocks);
+}
+
+hipError_t launch_expand(const LaunchShape& ls, hipStream_t stream, const KParams& p, const float* compact,
+                         long long rows, float* obs) {
+    if (rows <= 0) return hipSuccess;
+    KParams q = p;                 // same lane layout, `rows` envs instead of the handle's E
+    q.E = (int)rows;
+    const long long per_block = (long long)p.EW * p.waves_per_block;
+    const long long blocks = (rows + per_block - 1) / per_block;
+    if (rows > 0x7FFFFFFFll || blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    return launch_observe_any(ls, stream, q, KState{}, obs, reinterpret_cast<const float4*>(compact), (unsigned)blocks);
 }
 
 hipError_t launch_reset_from_pool(hipStream_t stream, const KParams& p, const KState& st,

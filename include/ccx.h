@@ -75,6 +75,8 @@ typedef struct ccx_params {
     double goal_reward, no_goal_reward, step_penalty;
 } ccx_params;
 
+typedef struct ccx_handle ccx_handle;
+
 /* per-agent result byte of one step ("agent_flags", u8 [E][N]) */
 #define CCX_AF_TERMINATED   0x01u /* terminateds[id] (always present, terminateds.py:40-82)             */
 #define CCX_AF_TRUNCATED    0x02u /* truncateds[id]; meaningful only with CCX_AF_LIVE (truncateds.py:56)  */
@@ -108,6 +110,7 @@ typedef struct ccx_step_out {
     double*  reward;       /* [E][N] f64, meaningful where CCX_AF_LIVE (rewards.py:44-182)      */
     uint8_t* agent_flags;  /* [E][N] CCX_AF_*                                                   */
     uint8_t* env_flags;    /* [E]    CCX_EF_*                                                   */
+    float*   obs_compact;  /* [E][N][4] CCX_OBS_COMPACT, see below                                 */
 } ccx_step_out;
 
 /* trajectory outputs of a K-step rollout; step s of env e lives at [s][e]...; NULL skips */
@@ -116,7 +119,23 @@ typedef struct ccx_rollout_out {
     double*  reward;       /* [K][E][N]    */
     uint8_t* agent_flags;  /* [K][E][N]    */
     uint8_t* env_flags;    /* [K][E]       */
+    float*   obs_compact;  /* [K][E][N][4] */
 } ccx_rollout_out;
+
+/*
+ * CCX_OBS_COMPACT -- an OPTIONAL second observation output for consumers that live on the GPU (next to,
+ * never instead of, the DefaultObservation layout).  A DefaultObservation row (observations.py:79-92) is six
+ * per-row numbers plus, for EVERY agent j of the env, (x_j, y_j, type_j, active_j): the N rows of an env
+ * repeat the same 4N numbers N times (152 of the 162 bytes a C2 agent-step writes).  obs_compact holds each
+ * agent's four numbers ONCE per env and step: f32 [..][E][N][4] = (x, y, type 0 boarding / 1 exiting,
+ * active 0/1), 16 bytes per agent-step instead of 16N + 24.  ccx_expand_observations turns compact rows back
+ * into the DefaultObservation rows with the very gather ccx_observe uses, bit for bit (rows = envs, or
+ * steps x envs for a trajectory): a policy network can consume the compact tensor directly, or expand just
+ * the mini-batch it samples.  The row constants (door centre, division_y, door_left, door_right) are those
+ * of the handle.
+ */
+int ccx_expand_observations(ccx_handle* h, const float* obs_compact /* [rows][N][4] */, int64_t rows,
+                            float* obs /* [rows][N][L] */);
 
 /* device-side counters accumulated by ccx_rollout (u64 each; ccx_read_counters copies to host) */
 typedef struct ccx_counters {
@@ -128,7 +147,6 @@ typedef struct ccx_counters {
     uint64_t arrivals;         /* deactivations (collectivecrossing.py:210-212)           */
 } ccx_counters;
 
-typedef struct ccx_handle ccx_handle;
 
 /* library / build info ------------------------------------------------------------------------ */
 int         ccx_abi_version(void);

@@ -216,3 +216,50 @@ def test_bench_direct_rccl_flag():
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert d["counters_allreduce"].startswith("ccx_rccl_allreduce_counters (1 RCCL rank")
     assert d["counters"]["env_steps"] == 2 * 500 * 1024
+
+
+# ---- CCX_OBS_COMPACT ------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g1_c1_random", "g2_c1_shuffled_absent", "g7_n5_odd", "g3_c3_dense_shuffled",
+                                  "g4_c5_all_at_dest_greedy_25_25", "g7_n1_boarding_only"])
+def test_compact_observations_expand_to_the_reference_rows(ccx, name):
+    """obs_compact holds (x, y, type, active) once per agent; ccx_expand_observations must rebuild the
+    DefaultObservation rows the reference recorded (observations.py:43-94) bit for bit -- from a rollout
+    that wrote ONLY the compact output, and from a step that wrote both."""
+    g = Golden(name)
+    env = ccx(g.config, g.E)
+    env.set_state(**g.init_state())
+    res = env.rollout(g["actions"], g["order"], want_obs=False, want_compact=True)
+    assert res.obs is None and tuple(res.obs_compact.shape) == (g.K, g.E, g.N, 4)
+    comp = _np(res.obs_compact)
+    nb = g.config.num_boarding_agents
+    np.testing.assert_array_equal(comp[..., 0], g["x"].astype(np.float32))
+    np.testing.assert_array_equal(comp[..., 1], g["y"].astype(np.float32))
+    np.testing.assert_array_equal(comp[..., 2], np.broadcast_to((np.arange(g.N) >= nb).astype(np.float32), comp[..., 2].shape))
+    np.testing.assert_array_equal(comp[..., 3], g["active"].astype(np.float32))
+    full = env.expand_observations(res.obs_compact)
+    np.testing.assert_array_equal(_np(full).view(np.uint32), g["obs"].view(np.uint32))
+    np.testing.assert_array_equal(_np(res.agent_flags), g["agent_flags"])
+    # one step with both outputs; expanding a single env's rows works too
+    env.set_state(**g.init_state())
+    r = env.step(g["actions"][0], g["order"][0], want_obs=True, want_compact=True)
+    np.testing.assert_array_equal(_np(env.expand_observations(r.obs_compact)).view(np.uint32), _np(r.obs).view(np.uint32))
+    one = env.expand_observations(r.obs_compact[g.E - 1])
+    np.testing.assert_array_equal(_np(one).view(np.uint32), g["obs"][0, g.E - 1].view(np.uint32))
+    env.close()
+
+
+def test_compact_rollout_with_autoreset_and_policy_equals_the_full_rollout(ccx):
+    g = Golden("g4_small_all_at_dest_greedy")
+    a, b = ccx(g.config, 700), ccx(g.config, 700)
+    for env in (a, b):
+        env.make_reset_pool(5, 97)
+        env.reset_from_pool()
+    full, acts_a = a.rollout_greedy(90, auto_reset=True)
+    out = b.alloc_rollout(90, want_obs=False, want_compact=True)
+    comp, acts_b = b.rollout_greedy(90, auto_reset=True, out=out)
+    np.testing.assert_array_equal(_np(acts_a), _np(acts_b))
+    np.testing.assert_array_equal(_np(b.expand_observations(comp.obs_compact)).view(np.uint32), _np(full.obs).view(np.uint32))
+    np.testing.assert_array_equal(_np(comp.reward).view(np.uint64), _np(full.reward).view(np.uint64))
+    assert a.counters() == b.counters()
+    a.close()
+    b.close()
