@@ -426,9 +426,10 @@ class BatchedCollectiveCrossing:
     def pace_state(self) -> dict[str, float]:
         """The pace controller's state (``ccx_get_pace_state``): next pace / floor in ns, launches since the
         last collapse, whether rollouts of this shape are paced at all."""
-        v = (C.c_float * 4)()
+        v = (C.c_float * 6)()
         check(self._lib.ccx_get_pace_state(self._h, v))
-        return dict(zip(("next_pace_ns", "floor_ns", "calm_launches", "paced"), (float(x) for x in v)))
+        return dict(zip(("next_pace_ns", "floor_ns", "calm_launches", "paced", "cliff_ns", "cliff_confirmations"),
+                        (float(x) for x in v)))
 
     def launch_shape(self) -> dict[str, int]:
         v = [C.c_int32() for _ in range(4)]

@@ -135,6 +135,19 @@ int choose_shape(ccx_handle* h) {
     // 4.43e9 vs 4.23e9 env-steps/s on C2; 3 or 4 per workgroup leave CUs idle and lose 5-10 %)
     int tpb = h->waves_per_block > 0 ? h->waves_per_block
               : (tiles > 8192 || (small_tiles && tiles >= 512)) ? 2 : 1;
+    // One round beats two (round 2): a CU holds 16 wavefronts of this kernel (4 per SIMD at its ~100
+    // VGPRs).  If the batch needs more than that with the writer count above but fits with ONE writer
+    // wave per tile, and that writer's share stays <= 36 store iterations per step, every tile is
+    // resident for the whole launch and the tiles of a step sweep the slab exactly once -- C3 (4096 x 32:
+    // 2048 tiles x 4 waves = two rounds) 0.84 -> 0.87 of the HBM peak with 1 writer and 4 tiles per
+    // workgroup.  (C5, 67 KB per tile, already fits one round with 3 writers; one writer is too slow there.)
+    if (h->writers == 0 && h->waves_per_block == 0 && !small_tiles) {
+        const long long cap = 16ll * h->num_cus;
+        if ((long long)tiles * (1 + writers) > cap && (long long)tiles * 2 <= cap && n4 <= 64 * 36) {
+            writers = 1;
+            tpb = 4;
+        }
+    }
     while (tpb > 1 && tpb * (1 + writers) > 8) --tpb;   // <= 512 threads per workgroup
     ccx::LaunchShape& s = h->shape;
     s.glog = glog;
@@ -229,15 +242,25 @@ int choose_shape(ccx_handle* h) {
     // would restart from ONE placement forever, so the stride is 1 then (env e walks e, e+1, e+2, ...)
     k.pool_stride = h->pool_size > 0 ? (long long)(h->total_envs % h->pool_size) : 0;
     if (h->pool_size > 0 && k.pool_stride == 0) k.pool_stride = 1 % h->pool_size;
-    // Write-window defaults (measured round 2).  Tiles served by several writer waves (tens of
-    // KB per tile and step: C3, C5) drain 5-10 % faster when the tiles of a round are phased over the step
+    // Write-window defaults (measured round 2).  Large tiles (tens of KB per tile and step:
+    // C3, C5) drain 5-10 % faster when the tiles of a round are phased over the step
     // period in tile order and groups of 16 adjacent tiles go to one XCD, dealt round-robin: the chip then
     // writes one window that sweeps through the slab instead of 1000+ regions at once (C3 0.80 -> 0.86,
     // C5-64 0.79 -> 0.89, C5-50 0.77 -> 0.83 of the HBM peak in one call).  Small single-writer tiles (C2)
     // show no difference and keep the common phase and the XCD-contiguous mapping.
-    const bool big_tiles = writers >= 2;
+    const bool big_tiles = !small_tiles;
     k.pace_phase = (uint32_t)(h->tun_pace_phase >= 0 ? h->tun_pace_phase : (big_tiles ? 1 : 0));
-    k.tile_map = (uint32_t)(h->tun_tile_map >= 0 ? h->tun_tile_map : (big_tiles ? 5 : 0));
+    // groups of ~1 MiB of one step's slab per XCD: g workgroups with g * (bytes a workgroup writes per step)
+    // closest to 1 MiB, a power of two in 1..32 (C5-64: 16 x 67 KB, C3: 8 x 137 KB)
+    int auto_map = 0;
+    if (big_tiles) {
+        const double wg_bytes = tile_bytes * tpb;
+        int g = 1;
+        while (g < 32 && wg_bytes * g * 1.41 < 1048576.0) g <<= 1;
+        auto_map = 1;
+        while ((1 << (auto_map - 1)) < g) ++auto_map;
+    }
+    k.tile_map = (uint32_t)(h->tun_tile_map >= 0 ? h->tun_tile_map : auto_map);
     k.writer_gap = (uint32_t)h->tun_writer_gap;
     k.writer_split = (uint32_t)h->tun_writer_split;
     return CCX_OK;
@@ -285,7 +308,7 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
         return fail(CCX_EINVAL, "obs_compact buffer must be 16-byte aligned");
     CCX_HIP(hipSetDevice(h->device));
     if (h->pace_dirty) {   // (re)start the pace controller: new handle, new launch shape or new setting
-        CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state), 0, 4, h->stream));   // floor = 0
+        CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state), 0, 8, h->stream));   // floor, cliff memory = 0
         CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state + h->pace_slot),
                                   (int)h->pace_init_fp, 1, h->stream));
         h->pace_dirty = false;
@@ -371,7 +394,7 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     alloc((void**)&h->st.episode, (size_t)h->E * 4);
     alloc((void**)&h->counters, ccx::counter_words(h->E) * sizeof(unsigned long long));
     alloc((void**)&h->placement_scratch, en * 2);
-    alloc((void**)&h->pace_state, 4 * sizeof(uint32_t));
+    alloc((void**)&h->pace_state, 8 * sizeof(uint32_t));
     alloc((void**)&h->input_errors, 2 * sizeof(unsigned long long));
     alloc((void**)&h->obs_table, kMaxObsUnits * sizeof(uint16_t));
     if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess ||
@@ -785,17 +808,19 @@ int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {
     return CCX_OK;
 }
 
-int ccx_get_pace_state(ccx_handle* h, float* out4) {
-    if (!h || !out4) return fail(CCX_EINVAL, "NULL argument");
+int ccx_get_pace_state(ccx_handle* h, float* out6) {
+    if (!h || !out6) return fail(CCX_EINVAL, "NULL argument");
     CCX_HIP(hipSetDevice(h->device));
     CCX_HIP(hipStreamSynchronize(h->stream));
-    uint32_t st[4];
+    uint32_t st[8];
     CCX_HIP(hipMemcpy(st, h->pace_state, sizeof(st), hipMemcpyDeviceToHost));
     auto ns = [](uint32_t fp) { return (float)((double)fp / 256.0 * 10.0); };
-    out4[0] = h->pace_dirty ? ns(h->pace_init_fp) : ns(st[h->pace_slot]);   // the vote the next launch reads
-    out4[1] = h->pace_dirty ? 0.0f : ns(st[2]);                             // floor
-    out4[2] = h->pace_dirty ? 0.0f : (float)st[3];                          // launches since the last collapse
-    out4[3] = h->kp.pace_state ? 1.0f : 0.0f;
+    out6[0] = h->pace_dirty ? ns(h->pace_init_fp) : ns(st[h->pace_slot]);   // the vote the next launch reads
+    out6[1] = h->pace_dirty ? 0.0f : ns(st[2]);                             // floor
+    out6[2] = h->pace_dirty ? 0.0f : (float)st[3];                          // launches since the last collapse
+    out6[3] = h->kp.pace_state ? 1.0f : 0.0f;
+    out6[4] = h->pace_dirty ? 0.0f : ns(st[4]);                             // pace of the last collapse (the cliff)
+    out6[5] = h->pace_dirty ? 0.0f : (float)st[5];                          // confirmations of that cliff
     return CCX_OK;
 }
 

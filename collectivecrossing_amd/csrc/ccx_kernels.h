@@ -31,7 +31,7 @@ struct KParams {
     uint32_t writer_vmcnt;               // >0: a writer starts a step only with <= this many of its stores in flight
     // step pacing (rollouts that write observations): every tile starts env-step s no earlier than
     // t0 + s * pace on the 100 MHz s_memrealtime clock; pace = *pace_state in ticks x 256 (0 = off)
-    uint32_t* pace_state;                // [pace_slot] is read, [pace_slot ^ 1] collects the votes, [2] = floor, [3] launches since the last collapse
+    uint32_t* pace_state;                // [pace_slot] is read, [pace_slot ^ 1] collects the votes, [2] = floor, [3] launches since the last collapse, [4] pace of the last collapse, [5] confirmations, [6] collapse mark of the running launch, [7] adaptive launches
     uint32_t pace_min_fp, pace_max_fp;
     uint32_t pace_slot;
     uint32_t resident_blocks;            // workgroups the device holds at once (0 = unknown)

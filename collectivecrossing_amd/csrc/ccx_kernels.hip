@@ -654,7 +654,8 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
         // [2] = floor: the pace just above the last collapse; it decays by 0.1 % per launch at first
         // and twice as fast after every 8 further launches without a collapse ([3] counts them), so
         // that a transient (the first milliseconds of a process collapse at paces that are fine
-        // later) does not hold the pace up for long while a persistent cliff is approached slowly
+        // later) does not hold the pace up for long while a persistent cliff is approached slowly;
+        // [4]..[7] = cliff memory (below)
         const uint32_t voted = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + p.pace_slot);
         const uint32_t floor_fp = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + 2);
         pace_base = __builtin_amdgcn_readfirstlane(voted > floor_fp ? voted : floor_fp);
@@ -675,7 +676,25 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
         if (p.pace_adapt && K >= 64 && tile == 0 && lane == 0) {
             p.pace_state[p.pace_slot ^ 1u] = 0u;               // the votes of this launch are collected here
             const uint32_t streak = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + 3);
-            const uint32_t sh = 10u - (streak >= 32u ? 4u : streak >> 3);
+            // Cliff memory: the collapsed tiles of the previous launch left its pace in [6].  A collapse
+            // within 3 % of the one before ([4]) confirms where the cliff of this box and shape is ([5]
+            // counts confirmations); from then on the floor is let down 40 times more slowly (0.024 % per
+            // launch, no acceleration), so the controller sits ~2 % above a cliff it knows instead of
+            // walking back into it every 15-20 launches.  Collapses during the first 16 launches of a
+            // controller do not count (a process collapses at paces that are fine a few milliseconds later).
+            const uint32_t mark = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + 6);
+            uint32_t confirmed = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + 5);
+            const uint32_t launches = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + 7);
+            if (mark) {
+                const uint32_t cliff = *reinterpret_cast<volatile const uint32_t*>(p.pace_state + 4);
+                const uint32_t gap = mark > cliff ? mark - cliff : cliff - mark;
+                if (launches >= 16u) confirmed = (cliff && gap < (cliff >> 5)) ? (confirmed < 8u ? confirmed + 1u : 8u) : 1u;
+                p.pace_state[4] = mark;
+                p.pace_state[5] = confirmed;
+                p.pace_state[6] = 0u;
+            }
+            p.pace_state[7] = launches < 100000u ? launches + 1u : launches;
+            const uint32_t sh = confirmed >= 2u ? 12u : 10u - (streak >= 32u ? 4u : streak >> 3);
             p.pace_state[2] = floor_fp - (floor_fp >> sh);
             p.pace_state[3] = streak < 1000u ? streak + 1u : streak;
         }
@@ -996,6 +1015,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                 next = pace_base + pace_base / 33u;
                 atomicMax(&p.pace_state[2], pace_base + pace_base / 40u);
                 p.pace_state[3] = 0u;
+                p.pace_state[6] = pace_base;                 // (every collapsed tile writes the same value)
             } else if (late) {
                 // half the relative overshoot, at least 0.5 %
                 unsigned long long over16 = ((elapsed_fp - planned_fp) << 16) / planned_fp;   // overshoot x 2^16

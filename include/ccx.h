@@ -326,10 +326,10 @@ int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight);
  * ccx_get_step_pace returns the pace in effect (synchronises).  Results never depend on it. */
 int ccx_set_step_pace(ccx_handle* h, int32_t ns_per_env_step);
 int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step);
-/* The controller's state for diagnostics and tests (synchronises): out4 = { the pace the next launch starts
+/* The controller's state for diagnostics and tests (synchronises): out6 = { the pace the next launch starts
  * from (ns), the floor just above the last collapse (ns), launches since that collapse, 1 if rollouts of this
- * shape are paced at all } */
-int ccx_get_pace_state(ccx_handle* h, float* out4);
+ * shape are paced at all, the pace of the last collapse = the cliff (ns), how often that cliff was confirmed } */
+int ccx_get_pace_state(ccx_handle* h, float* out6);
 /* Where the ADAPTIVE controller starts (ns per env-step; 0 = the library's assumption of 6.8 TB/s): a
  * caller that remembers the pace a previous handle of the same shape converged to (ccx_get_step_pace)
  * skips the descent of the first launches.  Restarts the controller. */

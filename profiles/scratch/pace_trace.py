@@ -18,7 +18,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 fixed = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # ns per env-step, -1 = pacing off, 0 = adaptive
 cfg, E = workload_config(wl)
-K = 500 if wl == "c2" else 100
+K = 500 if wl == "c2" else 250
 env = BatchedCollectiveCrossing(cfg, E)
 env.set_timing(True)
 if fixed:
@@ -32,4 +32,6 @@ print(f"{wl}: start pace {env.step_pace_ns():.0f} ns")
 for i in range(n):
     env.rollout(acts, auto_reset=True, out=traj)
     ms = env.last_launch_ms()
-    print(f"launch {i:2d}: {ms * 1000 / K:7.3f} us/env-step   next pace {env.step_pace_ns():7.0f} ns", flush=True)
+    st = env.pace_state()
+    print(f"launch {i:3d}: {ms * 1000 / K:7.3f} us/env-step   next pace {env.step_pace_ns():7.1f} ns  floor {st['floor_ns']:7.1f}  "
+          f"calm {st['calm_launches']:4.0f}  cliff {st['cliff_ns']:7.1f} x{st['cliff_confirmations']:.0f}", flush=True)

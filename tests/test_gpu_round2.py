@@ -65,13 +65,23 @@ def _against_oracle(oracle, ccx, g, E, K, seed, *, pool_size=257, setup=None, or
 
 def test_full_size_c3_equals_the_oracle(oracle, ccx):
     """BASELINE configs[2] at its full size: 4096 envs x (16 + 16) agents on the 20x12 grid, SimpleDistance,
-    dense collisions -- the exact launch the C3 bench figure comes from (more workgroups than the device
-    holds at once, step pacing on with the proportionally faster schedule of the partial last round)."""
+    dense collisions -- the exact launch the C3 bench figure comes from (one writer wave per tile and four
+    tiles per workgroup so that all 2048 tiles are resident in one round; tiles phased over the step period)."""
     g = Golden("g3_c3_dense_simple_distance")
     assert (g.N, g.config.width, g.config.height) == (32, 20, 12)
     c, shape, _, _ = _against_oracle(oracle, ccx, g, E=4096, K=18, seed=31, order=False)
-    assert shape["num_blocks"] > shape["resident_blocks"] > 0        # really more than one round
+    assert shape["writers_per_tile"] == 1 and shape["waves_per_block"] == 4
+    assert shape["num_blocks"] == shape["resident_blocks"] == 512       # one round
     assert c["env_steps"] == 4096 * 18 and c["moves"] > 0
+
+
+def test_c3_geometry_in_several_rounds_equals_the_oracle(oracle, ccx):
+    """More workgroups than the device holds at once (6001 envs: 3001 tiles x 4 waves, a partial last tile and
+    a partial last round whose schedule is scaled) -- the multi-round path of the pace logic."""
+    g = Golden("g3_c3_dense_simple_distance")
+    c, shape, _, _ = _against_oracle(oracle, ccx, g, E=6001, K=17, seed=33, order=False)
+    assert shape["num_blocks"] > shape["resident_blocks"] > 0 and shape["writers_per_tile"] == 3
+    assert c["env_steps"] == 6001 * 17
 
 
 def test_full_size_c3_shuffled_orders_equal_the_oracle(oracle, ccx):
@@ -263,3 +273,32 @@ def test_compact_rollout_with_autoreset_and_policy_equals_the_full_rollout(ccx):
     assert a.counters() == b.counters()
     a.close()
     b.close()
+
+
+def test_steady_state_launches_have_no_outliers(ccx):
+    """The adaptive pace controller in steady state: after the start-up phase, 60 consecutive
+    C2 launches (4096 envs x 8 agents, 500 env-steps each, full outputs) stay within a few per cent of their
+    median -- a collapse of the drain rate costs ~8 % of a launch and must be a rare event, not a rhythm."""
+    import torch
+
+    from bench import c2_config
+    E, K = 4096, 500
+    env = ccx(c2_config(), E)
+    env.set_timing(True)
+    env.make_reset_pool(0, 4096)
+    env.reset_from_pool()
+    acts = torch.randint(0, 5, (K, E, env.num_agents), dtype=torch.uint8, device=env.device)
+    traj = env.alloc_rollout(K)
+    for _ in range(100):
+        env.rollout(acts, auto_reset=True, out=traj)
+    ms = []
+    for _ in range(60):
+        env.rollout(acts, auto_reset=True, out=traj)
+        ms.append(env.last_launch_ms())
+    ms = np.array(ms)
+    med = float(np.median(ms))
+    over = int((ms > 1.05 * med).sum())
+    st = env.pace_state()
+    env.close()
+    assert st["paced"] == 1.0 and st["next_pace_ns"] > 0
+    assert over <= 1 and ms.max() < 1.15 * med, (over, ms.max() / med, sorted(ms)[-3:], st)
