@@ -261,8 +261,6 @@ int choose_shape(ccx_handle* h) {
         while ((1 << (auto_map - 1)) < g) ++auto_map;
     }
     k.tile_map = (uint32_t)(h->tun_tile_map >= 0 ? h->tun_tile_map : auto_map);
-    k.writer_gap = (uint32_t)h->tun_writer_gap;
-    k.writer_split = (uint32_t)h->tun_writer_split;
     return CCX_OK;
 }
 
@@ -779,8 +777,6 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
     struct { const char* name; int* slot; int lo, hi; } table[] = {
         {"pace_phase", &h->tun_pace_phase, -1, 3},
         {"tile_map", &h->tun_tile_map, -1, 6},
-        {"writer_gap", &h->tun_writer_gap, 0, 64},
-        {"writer_split", &h->tun_writer_split, 0, 1},
     };
     for (auto& t : table)
         if (strcmp(name, t.name) == 0) {
@@ -789,7 +785,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
             *t.slot = value;
             return choose_shape(h);
         }
-    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, writer_gap, writer_split)", name);
+    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map)", name);
 }
 
 int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {

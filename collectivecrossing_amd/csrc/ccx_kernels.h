@@ -42,9 +42,8 @@ struct KParams {
     long long env_offset;                // global index of env 0 (sharding)
     long long pool_size;                 // reset-pool entries (0 = none)
     long long pool_stride;               // cursor stride: total_envs mod pool_size, 1 when that is 0
-    // tunables (ccx_set_tunable): how the tiles' step schedules are phased, how workgroups map to tiles,
-    // pause between a writer's store iterations
-    uint32_t pace_phase, tile_map, writer_gap, writer_split;
+    // tunables (ccx_set_tunable): how the tiles' step schedules are phased, how workgroups map to tiles
+    uint32_t pace_phase, tile_map;
 };
 
 struct KState {

@@ -426,11 +426,13 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             const int n4l = n4 + (int)lead;               // one past the last slot of the shifted layout
             // my store iterations: it0, it0 + it_step, ... below it_end (one iteration = 64 vector units)
             const int total_its = (n4l + 63) >> 6;
-            // each writer takes one contiguous share of the region (+0.5 % on C3 / C5 under pacing); tunable
-            // writer_split = 1: writer w takes iterations w, w + nw, ... (the writers sweep the region together)
+            // each writer takes one contiguous share of the region (+0.5 % on C3 / C5 under pacing; interleaving
+            // the writers' 1-KiB iterations instead was +1 % on C3 with 3 writers, -1..2 % on C5-50, and the
+            // run-time stride cost the single-writer C2 path 3-5 %: not kept)
             const int per_w = (total_its + nw - 1) / nw;
-            const int it0 = p.writer_split ? w : w * per_w, it_step = p.writer_split ? nw : 1;
-            const int it_end = p.writer_split ? total_its : ((it0 + per_w) < total_its ? (it0 + per_w) : total_its);
+            const int it0 = w * per_w;
+            constexpr int it_step = 1;
+            const int it_end = (it0 + per_w) < total_its ? (it0 + per_w) : total_its;
             // LDS source addresses of this lane's first kFastObsIters observation stores
             uint32_t oa0[kFastObsIters], oa1[kFastObsIters];
 #pragma unroll
@@ -516,8 +518,6 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                                     }
                                 }
                             }
-                            // tunable: spread a writer's store iterations over the step period
-                            for (uint32_t z = 0; z < p.writer_gap; ++z) __builtin_amdgcn_s_sleep(2);
                         }
                     }
                     // beyond the register-cached iterations: table-driven

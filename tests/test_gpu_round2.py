@@ -90,8 +90,7 @@ def test_full_size_c3_shuffled_orders_equal_the_oracle(oracle, ccx):
 
 
 @pytest.mark.parametrize("knobs", [{"pace_phase": 0, "tile_map": 0}, {"pace_phase": 1, "tile_map": 1}, {"pace_phase": 2, "tile_map": 4},
-                                   {"pace_phase": 3, "tile_map": 0, "writer_split": 1},
-                                   {"pace_phase": 1, "tile_map": 6, "writer_gap": 3}])
+                                   {"pace_phase": 3, "tile_map": 0}, {"pace_phase": 1, "tile_map": 6}])
 @pytest.mark.parametrize("cfg_name,E,K", [("g1_c1_random", 4096, 70), ("g3_c3_dense_simple_distance", 1500, 20)])
 def test_tunables_never_change_results(oracle, ccx, cfg_name, E, K, knobs):
     def setup(env):
