@@ -362,7 +362,8 @@ class BatchedCollectiveCrossing:
     def _pace_key(self) -> str:
         s = self.launch_shape()
         c = self.config
-        name = torch.cuda.get_device_properties(self.device).name
+        props = torch.cuda.get_device_properties(self.device)
+        name = str(getattr(props, "gcnArchName", "") or props.name).split(":")[0]    # "gfx950" (the marketing name varies)
         return (f"{name}|grid{c.width}x{c.height}|E{self.num_envs}|N{self.num_agents}|lanes{s['lanes_per_wave']}"
                 f"|tpb{s['waves_per_block']}|w{s['writers_per_tile']}")
 
