@@ -279,12 +279,16 @@ constexpr int kObsBatch = 5;       // LDS reads issued back to back before their
 
 //   PLAIN  the caller passed neither a move order nor a policy (the bench line, plain RL stepping): the step
 //        loop is compiled without those branches (12 % fewer cycles per env-step on the sim chain).
-template <int GLOG, bool PAIR, bool OUT, bool OCC, bool PLAIN>
+//   OUTM 0 = no trajectory outputs, 1 = outputs, 2 = outputs whose tile regions do not begin / end on 128-byte
+//        lines (edge iterations, below; a separate instantiation because the single-writer C2 path loses 4-5 %
+//        to ANY extra instruction in its store loop, even a never-taken branch)
+template <int GLOG, bool PAIR, int OUTM, bool OCC, bool PLAIN>
 __global__ void __launch_bounds__(512)
 rollout_kernel(const KParams p, const KState st, const unsigned long long* __restrict__ cell_info,
                const uint8_t* __restrict__ actions, const uint8_t* __restrict__ order, const int K,
                const int auto_reset, const uint8_t* __restrict__ pool, const KOut out,
                unsigned long long* counters, const int policy_arg, uint8_t* __restrict__ actions_out) {
+    constexpr bool OUT = OUTM != 0, EDGE = OUTM == 2;
     const int policy = PLAIN ? 0 : policy_arg;
     using mask_t = typename GroupMask<GLOG>::type;
     constexpr int G = 1 << GLOG;
@@ -433,6 +437,20 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             const int it0 = w * per_w;
             constexpr int it_step = 1;
             const int it_end = (it0 + per_w) < total_its ? (it0 + per_w) : total_its;
+            // Edge iterations.  A region that does not begin / end on a 128-byte line (N = 50: rows of 824 bytes)
+            // shares its first and last line with the neighbouring tiles' regions: two partial writes of one
+            // line from two workgroups.  Streamed (`nt`) they reach memory as two partial-line writes; written
+            // with plain stores the first and the last iteration of a region stay in L2, where the halves
+            // merge (the grouped tile map keeps neighbours on one XCD) -- C5-50 0.83 -> 0.86 of the HBM peak,
+            // aligned shapes (C2, C3, C5-64) have no edge iteration and take the unchanged path.
+            const int edge_first = (EDGE && lead != 0u && it0 == 0) ? 0 : -1;
+            const int edge_last = (EDGE && (((uint32_t)n4l * vbytes) & 127u) != 0u && it_end == total_its) ? total_its - 1 : -1;
+            uint32_t edge_mask = 0;   // over my register-cached iterations
+            if (EDGE && want_obs) {
+                if (edge_first >= 0) edge_mask |= 1u;
+                if (edge_last >= it0 && edge_last - it0 < kFastObsIters) edge_mask |= 1u << (edge_last - it0);
+            }
+            edge_mask = __builtin_amdgcn_readfirstlane(edge_mask);
             // LDS source addresses of this lane's first kFastObsIters observation stores
             uint32_t oa0[kFastObsIters], oa1[kFastObsIters];
 #pragma unroll
@@ -505,16 +523,36 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                                 if constexpr (PAIR)
                                     vb[j] = *reinterpret_cast<const float2*>(sbase + oa1[j0 + j]);
                             }
+                            const uint32_t em = EDGE ? (edge_mask >> j0) & ((1u << kObsBatch) - 1u) : 0u;   // wave-uniform
+                            if (!EDGE || em == 0u) {
 #pragma unroll
-                            for (int j = 0; j < kObsBatch; ++j) {
-                                const uint32_t q = (uint32_t)(lane + 64 * (it0 + it_step * (j0 + j))) - lead;
-                                if ((it0 + it_step * (j0 + j)) < it_end && q < (uint32_t)n4) {
-                                    char* dst = obs_s + (q0_off + (uint32_t)(j0 + j) * it_stride);
-                                    if constexpr (PAIR) {
-                                        v4f v = {va[j].x, va[j].y, vb[j].x, vb[j].y};
-                                        store_obs(v, reinterpret_cast<v4f*>(dst));
-                                    } else {
-                                        store_obs(va[j], reinterpret_cast<float2*>(dst));
+                                for (int j = 0; j < kObsBatch; ++j) {
+                                    const uint32_t q = (uint32_t)(lane + 64 * (it0 + it_step * (j0 + j))) - lead;
+                                    if ((it0 + it_step * (j0 + j)) < it_end && q < (uint32_t)n4) {
+                                        char* dst = obs_s + (q0_off + (uint32_t)(j0 + j) * it_stride);
+                                        if constexpr (PAIR) {
+                                            v4f v = {va[j].x, va[j].y, vb[j].x, vb[j].y};
+                                            store_obs(v, reinterpret_cast<v4f*>(dst));
+                                        } else {
+                                            store_obs(va[j], reinterpret_cast<float2*>(dst));
+                                        }
+                                    }
+                                }
+                            } else {   // a batch that holds the region's first or last iteration (misaligned regions only)
+#pragma unroll
+                                for (int j = 0; j < kObsBatch; ++j) {
+                                    const uint32_t q = (uint32_t)(lane + 64 * (it0 + it_step * (j0 + j))) - lead;
+                                    if ((it0 + it_step * (j0 + j)) < it_end && q < (uint32_t)n4) {
+                                        char* dst = obs_s + (q0_off + (uint32_t)(j0 + j) * it_stride);
+                                        const bool edge = (em >> j) & 1u;
+                                        if constexpr (PAIR) {
+                                            v4f v = {va[j].x, va[j].y, vb[j].x, vb[j].y};
+                                            if (edge) *reinterpret_cast<v4f*>(dst) = v;
+                                            else store_obs(v, reinterpret_cast<v4f*>(dst));
+                                        } else {
+                                            if (edge) *reinterpret_cast<float2*>(dst) = va[j];
+                                            else store_obs(va[j], reinterpret_cast<float2*>(dst));
+                                        }
                                     }
                                 }
                             }
@@ -530,10 +568,12 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                             float2 a2 = *reinterpret_cast<const float2*>(sbase + (t & 0xFFFFu));
                             float2 b2 = *reinterpret_cast<const float2*>(sbase + (t >> 16));
                             v4f v = {a2.x, a2.y, b2.x, b2.y};
-                            store_obs(v, reinterpret_cast<v4f*>(obs_s + (size_t)ql * 16));
+                            if (EDGE && it == edge_last) *reinterpret_cast<v4f*>(obs_s + (size_t)ql * 16) = v;
+                            else store_obs(v, reinterpret_cast<v4f*>(obs_s + (size_t)ql * 16));
                         } else {
-                            store_obs(*reinterpret_cast<const float2*>(sbase + table[q]),
-                                      reinterpret_cast<float2*>(obs_s + (size_t)ql * 8));
+                            const float2 v2 = *reinterpret_cast<const float2*>(sbase + table[q]);
+                            if (EDGE && it == edge_last) *reinterpret_cast<float2*>(obs_s + (size_t)ql * 8) = v2;
+                            else store_obs(v2, reinterpret_cast<float2*>(obs_s + (size_t)ql * 8));
                         }
                     }
 #ifndef CCX_SAME_SLAB   /* diagnostic: every step overwrites slab 0 (L2-resident) */
@@ -1162,7 +1202,7 @@ __global__ void reset_from_pool_kernel(const KParams p, const KState st,
 // ---------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------
-template <int GLOG, bool PAIR, bool OUT, bool OCC, bool PLAIN>
+template <int GLOG, bool PAIR, int OUT, bool OCC, bool PLAIN>
 static hipError_t launch_rollout_v(const LaunchShape& ls, hipStream_t stream, const KParams& p,
                                    const KState& st, const unsigned long long* cell_info,
                                    const uint8_t* actions, const uint8_t* order, int K,
@@ -1188,23 +1228,27 @@ static hipError_t launch_rollout_g(const LaunchShape& ls, hipStream_t stream, co
                                    unsigned long long* counters, int policy, uint8_t* actions_out) {
     const bool pair = (p.N % 2) == 0;
     const bool want_out = out.obs || out.reward || out.agent_flags || out.env_flags || out.obs_compact || actions_out;
-    const int sel = (pair ? 4 : 0) | (want_out ? 2 : 0) | (ls.occ ? 1 : 0);
+    // edge iterations: the tile regions of the observation output share 128-byte lines with their neighbours
+    const size_t tile_region = (size_t)p.EW * p.N * (6 + 4 * p.N) * 4u, slab = (size_t)p.E * p.N * (6 + 4 * p.N) * 4u;
+    const bool edges = out.obs && (((tile_region | slab) & 127u) != 0 || (reinterpret_cast<uintptr_t>(out.obs) & 127u) != 0);
+    const int outm = want_out ? (edges ? 2 : 1) : 0;
     const bool plain = order == nullptr && policy == 0;
-#define CCX_GO(P_, O_, C_)                                                                                   \
+#define CCX_GO2(P_, O_, C_)                                                                                  \
     return plain ? launch_rollout_v<GLOG, P_, O_, C_, true>(ls, stream, p, st, cell_info, actions, order, K, \
                                                             auto_reset, pool, out, counters, policy, actions_out) \
                  : launch_rollout_v<GLOG, P_, O_, C_, false>(ls, stream, p, st, cell_info, actions, order, K, \
                                                              auto_reset, pool, out, counters, policy, actions_out)
-    switch (sel) {
-    case 7: CCX_GO(true, true, true);
-    case 6: CCX_GO(true, true, false);
-    case 5: CCX_GO(true, false, true);
-    case 4: CCX_GO(true, false, false);
-    case 3: CCX_GO(false, true, true);
-    case 2: CCX_GO(false, true, false);
-    case 1: CCX_GO(false, false, true);
-    default: CCX_GO(false, false, false);
+#define CCX_GO(P_, C_)                \
+    switch (outm) {                   \
+    case 2: CCX_GO2(P_, 2, C_);       \
+    case 1: CCX_GO2(P_, 1, C_);       \
+    default: CCX_GO2(P_, 0, C_);      \
     }
+    if (pair && ls.occ) { CCX_GO(true, true) }
+    else if (pair) { CCX_GO(true, false) }
+    else if (ls.occ) { CCX_GO(false, true) }
+    else { CCX_GO(false, false) }
+#undef CCX_GO2
 #undef CCX_GO
 }
 
@@ -1215,7 +1259,7 @@ static int blocks_per_cu_g(const LaunchShape& ls, bool pair) {
     hipError_t e = hipSuccess;
 #define CCX_OCCQ(P_, C_)                                                                          \
     do {                                                                                          \
-        const void* f = reinterpret_cast<const void*>(&rollout_kernel<GLOG, P_, true, C_, true>);       \
+        const void* f = reinterpret_cast<const void*>(&rollout_kernel<GLOG, P_, 1, C_, true>);       \
         if (ls.lds_bytes > 60 * 1024)                                                             \
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, threads, ls.lds_bytes);           \
