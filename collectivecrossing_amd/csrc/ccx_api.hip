@@ -120,6 +120,28 @@ int choose_shape(ccx_handle* h) {
         if (need(1) <= 96u * 1024u)
             while (ew > 1 && need(ew) > 96u * 1024u) ew >>= 1;
     }
+    // Batches too small to be memory-bound (round 2): one env-step of a tile takes the sim chain's ~0.5 us
+    // whatever the tile holds, so what counts is that no writer wave takes longer than that and that every
+    // wave has a SIMD of its own.  Full 64-lane tiles with TWO writer waves each do both as long as
+    // 3 waves x tiles stays near the 1024 SIMDs: C2 geometry, us per env-step, full tiles + 2 writers vs the
+    // half-empty single-writer tiles chosen before: 1024 envs 0.53 vs 0.58, 2048 envs 0.54 vs 0.59 (0.63 vs
+    // 0.58 of the HBM peak), 3072 envs 0.63 vs 0.72 (0.81 vs 0.70).
+    bool small_batch = false;
+    if (h->lanes_per_wave == 0 && h->writers == 0 && h->waves_per_block == 0) {
+        const long long full_tiles = (h->E + max_ew - 1) / max_ew;
+        const int full_n4 = max_ew * h->N * (3 + 2 * h->N) / ((h->N % 2 == 0) ? 2 : 1);
+        if (full_n4 <= 64 * 12 && full_tiles * 3 <= 1400 && full_tiles * max_ew >= 256) {
+            auto up = [](size_t v) { return (v + 15u) & ~(size_t)15u; };   // (only if the LDS tables of a full tile fit)
+            const size_t cells_ = (size_t)(h->params.width + 3) * (size_t)(h->params.height + 3);
+            const size_t msz_ = (glog == 6) ? 8u : 4u;
+            const size_t units_ = (size_t)max_ew * h->N * (3 + 2 * h->N);
+            if (up(cells_ * 8u) + up(256u + 2048u + 2u * 1056u + up((size_t)max_ew * 2u * (cells_ + 1u) * msz_)) +
+                    up((units_ + 2u) * 2u) <= 96u * 1024u) {
+                small_batch = true;
+                ew = max_ew;
+            }
+        }
+    }
     const int tiles = (h->E + ew - 1) / ew;
     // writer waves per tile: enough that a writer handles <= ~6 store iterations per step
     const int units = ew * h->N * (3 + 2 * h->N);
@@ -129,12 +151,12 @@ int choose_shape(ccx_handle* h) {
     // regulator when step pacing is off and a safety net when it is on).
     // Larger tiles: 2-3 writers, no throttle (measured: no effect).
     const bool small_tiles = n4 <= 64 * 12;
-    int writers = h->writers > 0 ? h->writers : (n4 > 64 * 24 ? 3 : small_tiles ? 1 : 2);
+    int writers = h->writers > 0 ? h->writers : small_batch ? 2 : (n4 > 64 * 24 ? 3 : small_tiles ? 1 : 2);
     if (writers > 7) writers = 7;
     // tiles per workgroup: two small tiles share one cell table / one CU slot (with the throttle:
     // 4.43e9 vs 4.23e9 env-steps/s on C2; 3 or 4 per workgroup leave CUs idle and lose 5-10 %)
     int tpb = h->waves_per_block > 0 ? h->waves_per_block
-              : (tiles > 8192 || (small_tiles && tiles >= 512)) ? 2 : 1;
+              : small_batch ? 1 : (tiles > 8192 || (small_tiles && tiles >= 512)) ? 2 : 1;
     // One round beats two (round 2): a CU holds 16 wavefronts of this kernel (4 per SIMD at its ~100
     // VGPRs).  If the batch needs more than that with the writer count above but fits with ONE writer
     // wave per tile, and that writer's share stays <= 36 store iterations per step, every tile is
@@ -317,13 +339,25 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
                                                  h->input_errors);
         if (ce != hipSuccess) return fail(CCX_EHIP, "input check kernel launch failed: %s", hipGetErrorString(ce));
     }
+    // A launch that is being captured into a HIP graph is replayed with these very arguments: the controller
+    // cannot adapt across replays (the slot flip below happens once, at capture time), so such a launch runs
+    // at the pace in effect and neither votes nor touches the controller's state.
+    ccx::KParams kp = h->kp;
+    const bool adaptive = kp.pace_state && kp.pace_adapt && out.obs && K >= 64;
+    bool capturing = false;
+    if (adaptive) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess) (void)hipGetLastError();
+        else capturing = cap != hipStreamCaptureStatusNone;
+        if (capturing) kp.pace_adapt = 0u;
+    }
     int rc = begin_timed(h);
     if (rc) return rc;
-    hipError_t e = ccx::launch_rollout(h->shape, h->stream, h->kp, h->st, h->cell_info, actions,
+    hipError_t e = ccx::launch_rollout(h->shape, h->stream, kp, h->st, h->cell_info, actions,
                                        order, K, auto_reset, h->pool, out, h->counters, policy, actions_out);
     if (e != hipSuccess) return fail(CCX_EHIP, "rollout kernel launch failed: %s", hipGetErrorString(e));
     // the kernel collected the votes for the next pace in the other slot (same condition as in the kernel)
-    if (h->kp.pace_state && h->kp.pace_adapt && out.obs && K >= 64) h->pace_slot ^= 1u;
+    if (adaptive && !capturing) h->pace_slot ^= 1u;
     return end_timed(h);
 }
 

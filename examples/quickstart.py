@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Quick start on an MI355X: the reference's README example through the drop-in dict API, then the
-same config as a 4096-env batch (random actions, then the on-device greedy policy)."""
+same config as a 4096-env batch (random actions, the on-device greedy policy, the compact observation
+output) and as a vector env with per-env dict views."""
 
 import sys
 import time
@@ -43,4 +44,23 @@ print(f"random rollout: {E * K / dt:.3e} env-steps/s, obs {tuple(traj.obs.shape)
 traj, chosen = batch.rollout_greedy(K, auto_reset=True, out=traj)
 print("greedy rollout: mean live reward", float(traj.reward[traj.agent_flags & 4 != 0].mean()),
       "episodes so far", batch.counters()["episodes"])
+
+# 4. consumers on the GPU: (x, y, type, active) once per agent instead of the N-fold rows; expand what you sample
+del traj
+small = batch.rollout(actions, auto_reset=True, want_obs=False, want_compact=True)
+rows = batch.expand_observations(small.obs_compact[K - 1])          # [E, N, L], bit-equal to the DefaultObservation rows
+print("compact rollout:", tuple(small.obs_compact.shape), "-> expanded last step", tuple(rows.shape))
 batch.close()
+
+# 5. many envs behind the reference's dict API: one batch, lazy per-env dicts, per-policy row blocks on the device
+from collectivecrossing_amd.vector import VectorCollectiveCrossing  # noqa: E402
+
+vec = VectorCollectiveCrossing(config, 256)
+vec.reset(torch.arange(256, dtype=torch.int64))
+for _ in range(10):
+    vec.step_dicts([{a: vec.action_space.sample() for a in view.agents} for view in vec.envs], auto_reset=True)
+obs, rewards, terminateds, truncateds, infos = vec.view(17)
+blocks = vec.policy_inputs()
+print("vector env 17:", sorted(obs)[:2], "...; boarding block", tuple(blocks["boarding"]["obs"].shape),
+      "exiting block", tuple(blocks["exiting"]["obs"].shape))
+vec.close()

@@ -301,3 +301,42 @@ def test_steady_state_launches_have_no_outliers(ccx):
     env.close()
     assert st["paced"] == 1.0 and st["next_pace_ns"] > 0
     assert over <= 1 and ms.max() < 1.15 * med, (over, ms.max() / med, sorted(ms)[-3:], st)
+
+
+@pytest.mark.parametrize("E", [1024, 2048, 3072])
+def test_small_batches_use_full_tiles_with_two_writers_and_equal_the_oracle(oracle, ccx, E):
+    """Below the memory-bound regime the default shape is full 64-lane tiles with two writer waves each
+    (DESIGN.md 4): same results, of course."""
+    g = Golden("g8_rollout_c1")
+    c, shape, _, _ = _against_oracle(oracle, ccx, g, E=E, K=70, seed=17 + E)
+    assert (shape["lanes_per_wave"], shape["writers_per_tile"], shape["waves_per_block"]) == (64, 2, 1)
+    assert c["episodes"] > 0
+
+
+def test_a_paced_rollout_captured_into_a_graph_replays_without_touching_the_controller(ccx):
+    import torch
+
+    from bench import c2_config
+    E, K = 4096, 64
+    env = ccx(c2_config(), E)
+    env.make_reset_pool(0, 512)
+    env.reset_from_pool()
+    acts = torch.randint(0, 5, (K, E, env.num_agents), dtype=torch.uint8, device=env.device)
+    traj = env.alloc_rollout(K)
+    side = torch.cuda.Stream(device=env.device)
+    env.use_stream(side)
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            env.rollout(acts, auto_reset=True, out=traj)        # adaptive launches outside the capture
+        side.synchronize()
+        before = env.pace_state()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            env.rollout(acts, auto_reset=True, out=traj)
+        for _ in range(5):
+            graph.replay()
+        side.synchronize()
+    after = env.pace_state()
+    assert after["next_pace_ns"] == before["next_pace_ns"] and after["calm_launches"] == before["calm_launches"]
+    assert env.counters()["env_steps"] == (3 + 5) * K * E
+    env.close()
