@@ -292,9 +292,10 @@ def parse_args(argv=None):
     ap.add_argument("--pool", type=int, default=4096, help="reset-pool entries (seeds 0..pool-1)")
     ap.add_argument("--throttle", type=int, default=0, help="stores a writer keeps in flight (0=auto, -1=off)")
     ap.add_argument("--pace", type=int, default=0, help="ns per env-step (0=adaptive, -1=off)")
-    ap.add_argument("--policy", default="random", choices=["random", "greedy"],
+    ap.add_argument("--policy", default="random", choices=["random", "greedy", "device-random"],
                     help="random = actions from a device tensor (the bench line); greedy = the "
-                         "reference's GreedyPolicy(epsilon=0) evaluated inside the rollout kernel (BASELINE configs[4])")
+                         "reference's GreedyPolicy(epsilon=0) evaluated inside the rollout kernel (BASELINE configs[4]); "
+                         "device-random = uniform actions drawn inside the kernel (CCX_POLICY_RANDOM), no action tensor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the no-obs / K=1 secondary figures")
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip the observation output")
@@ -404,6 +405,8 @@ def run_rank(args) -> int:
                 e0.record()
             if args.policy == "greedy":
                 env.rollout_greedy(chunk, auto_reset=True, out=view, want_actions=False)
+            elif args.policy == "device-random":
+                env.rollout_policy(chunk, "random", auto_reset=True, out=view, want_actions=False)
             else:
                 a0 = (launched % n_buf) * chunk
                 env.rollout(actions[a0:a0 + chunk], auto_reset=True, out=view)

@@ -21,7 +21,8 @@ TRUNCATED_MODES = {"max_steps": 0, "custom": 0}  # truncateds.py:64-95: same ari
 ACTION_ABSENT = 255
 POLICY_GREEDY = 1
 POLICY_WAITING = 2
-POLICIES = {"greedy": POLICY_GREEDY, "waiting": POLICY_WAITING}
+POLICY_RANDOM = 3
+POLICIES = {"greedy": POLICY_GREEDY, "waiting": POLICY_WAITING, "random": POLICY_RANDOM}
 
 # agent_flags bits
 AF_TERMINATED, AF_TRUNCATED, AF_LIVE, AF_OBS = 0x01, 0x02, 0x04, 0x08
@@ -108,6 +109,7 @@ PROTOTYPES: dict[str, tuple] = {
                                      C.c_void_p]),
     "ccx_set_check_inputs": (C.c_int, [_H, C.c_int32]),
     "ccx_check_inputs": (C.c_int, [_H]),
+    "ccx_set_rng_seed": (C.c_int, [_H, C.c_uint64]),
     "ccx_zero_counters": (C.c_int, [_H]),
     "ccx_read_counters": (C.c_int, [_H, C.POINTER(CcxCounters)]),
     "ccx_counters_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p)]),

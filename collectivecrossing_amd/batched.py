@@ -316,6 +316,15 @@ class BatchedCollectiveCrossing:
         self._rollouts_with_obs += int(out.obs is not None and K >= 64)
         return out, actions_out
 
+    def rollout_policy(self, num_steps: int, policy: str, auto_reset: bool = False, **kw):
+        """``ccx_rollout_policy`` under its general name: "greedy", "waiting" or "random" (uniform actions drawn
+        on the device, seeded by :meth:`set_rng_seed`)."""
+        return self.rollout_greedy(num_steps, auto_reset=auto_reset, policy=policy, **kw)
+
+    def set_rng_seed(self, seed: int) -> None:
+        """Seed of the on-device action RNG (``CCX_POLICY_RANDOM``)."""
+        check(self._lib.ccx_set_rng_seed(self._h, int(seed) & (2**64 - 1)))
+
     # ------------------------------------------------------------------ counters / timing / shape
     def zero_counters(self) -> None:
         check(self._lib.ccx_zero_counters(self._h))

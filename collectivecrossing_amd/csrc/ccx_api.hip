@@ -678,8 +678,9 @@ int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t
                        const ccx_rollout_out* out, uint8_t* actions_out) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");
     if (num_steps < 1) return fail(CCX_EINVAL, "num_steps must be >= 1");
-    if (policy != CCX_POLICY_GREEDY && policy != CCX_POLICY_WAITING) return fail(CCX_EINVAL, "unknown policy %d", policy);
-    if (!h->shape.occ)
+    if (policy != CCX_POLICY_GREEDY && policy != CCX_POLICY_WAITING && policy != CCX_POLICY_RANDOM)
+        return fail(CCX_EINVAL, "unknown policy %d", policy);
+    if (!h->shape.occ && policy != CCX_POLICY_RANDOM)
         return fail(CCX_EINVAL, "policy rollouts need the LDS occupancy tables, which do not fit for this "
                     "grid / envs-per-wave; drive ccx_step with ccx_greedy_actions instead");
     if (auto_reset && (!h->pool || h->pool_size <= 0))
@@ -721,6 +722,13 @@ int ccx_check_inputs(ccx_handle* h) {
     CCX_HIP(hipSetDevice(h->device));
     CCX_HIP(hipStreamSynchronize(h->stream));
     return report_input_errors(h);
+}
+
+int ccx_set_rng_seed(ccx_handle* h, uint64_t seed) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    h->kp.rng_lo = (uint32_t)seed;
+    h->kp.rng_hi = (uint32_t)(seed >> 32);
+    return CCX_OK;
 }
 
 int ccx_zero_counters(ccx_handle* h) {

@@ -9,7 +9,18 @@ enum : uint32_t { CCX_K_ABSENT = 255u };
 enum : int { CCX_K_REWARD_DEFAULT = 0, CCX_K_REWARD_SIMPLE_DISTANCE = 1, CCX_K_REWARD_BINARY = 2,
              CCX_K_REWARD_CONSTANT_NEGATIVE = 3 };
 enum : int { CCX_K_TERM_INDIVIDUAL = 0, CCX_K_TERM_ALL = 1 };
-enum : int { CCX_K_POLICY_GREEDY = 1, CCX_K_POLICY_WAITING = 2 };
+enum : int { CCX_K_POLICY_GREEDY = 1, CCX_K_POLICY_WAITING = 2, CCX_K_POLICY_RANDOM = 3 };
+
+// CCX_POLICY_RANDOM: the action of agent `agent` of global env `genv` at step `step` (0-based) of its episode
+// `episode` -- a counter-based hash (lowbias32 rounds), uniform over 0..4 up to 2^-32; identical in the oracle
+__host__ __device__ inline uint32_t random_action(uint32_t seed_lo, uint32_t seed_hi, uint32_t genv, uint32_t episode,
+                                                  uint32_t step, uint32_t agent) {
+    uint32_t k = genv * 0x9E3779B1u + episode * 0x85EBCA77u + step * 0xC2B2AE3Du + agent * 0x27D4EB2Fu + seed_lo;
+    k ^= k >> 16; k *= 0x7FEB352Du; k ^= k >> 15; k *= 0x846CA68Bu; k ^= k >> 16;
+    k ^= seed_hi;
+    k ^= k >> 16; k *= 0x7FEB352Du; k ^= k >> 15; k *= 0x846CA68Bu; k ^= k >> 16;
+    return (uint32_t)(((unsigned long long)k * 5ull) >> 32);
+}
 enum : uint32_t { CCX_K_EF_ALL_TERM = 1u, CCX_K_EF_ALL_TRUNC = 2u, CCX_K_EF_RESET = 4u };
 
 // kernel parameters (passed by value; lives in SGPRs / the kernarg segment)
@@ -44,6 +55,7 @@ struct KParams {
     long long pool_stride;               // cursor stride: total_envs mod pool_size, 1 when that is 0
     // tunables (ccx_set_tunable): how the tiles' step schedules are phased, how workgroups map to tiles
     uint32_t pace_phase, tile_map;
+    uint32_t rng_lo, rng_hi;             // seed of CCX_POLICY_RANDOM (ccx_set_rng_seed)
 };
 
 struct KState {

@@ -820,8 +820,19 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
             //         published first; a direction is free if the current cell's word says the
             //         neighbour is enterable and no other active agent's bit sits on it.
             uint32_t a_out = a;
+            const bool occ_policy = policy == CCX_K_POLICY_GREEDY || policy == CCX_K_POLICY_WAITING;
+            if (policy == CCX_K_POLICY_RANDOM) {
+                // uniform random actions drawn ON THE DEVICE (ccx_rollout's rng_seed): a counter-based
+                // hash of (seed, global env, episode, step of the episode, agent slot), so the stream of an env does
+                // not depend on how launches are split or on the world size
+                const uint32_t asked = validbit & ~(term | trunc);
+                const uint32_t r = random_action(p.rng_lo, p.rng_hi, (uint32_t)(p.env_offset + env), (uint32_t)episode,
+                                                 (uint32_t)stepc, (uint32_t)i);
+                a = asked ? r : 4u;
+                a_out = asked ? r : (uint32_t)CCX_K_ABSENT;
+            }
             if constexpr (OCC) {
-                if (policy) {
+                if (occ_policy) {
                     const mask_t mybit0 = mask_t(1) << rank;
                     mask_t* const o_p0 = reinterpret_cast<mask_t*>(smem + occ_base + (act ? (uint32_t)c * msz : dump_off));
                     __hip_atomic_fetch_or(o_p0, mybit0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -866,7 +877,7 @@ rollout_kernel(const KParams p, const KState st, const unsigned long long* __res
                 const uint32_t r_off = (uint32_t)np * msz;
                 mask_t* const o_p = reinterpret_cast<mask_t*>(smem + o_addr);
                 mask_t* const q_p = reinterpret_cast<mask_t*>(smem + q_addr);
-                if (!policy)   // (already published for the policy)
+                if (!occ_policy)   // (already published for the scripted policies)
                     __hip_atomic_fetch_or(o_p, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __hip_atomic_fetch_or(q_p, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 wave_lds_sync();

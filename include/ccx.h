@@ -47,7 +47,7 @@ enum { CCX_TERM_INDIVIDUAL_AT_DESTINATION = 0, CCX_TERM_ALL_AT_DESTINATION = 1 }
 enum { CCX_TRUNC_MAX_STEPS = 0 };
 
 /* scripted policies evaluated on the device (src/baseline_policies/) */
-enum { CCX_POLICY_GREEDY = 1, CCX_POLICY_WAITING = 2 };
+enum { CCX_POLICY_GREEDY = 1, CCX_POLICY_WAITING = 2, CCX_POLICY_RANDOM = 3 };
 
 /* action codes, actions.py:8-24; CCX_ACTION_ABSENT = agent not in action_dict (it does not move,
  * collectivecrossing.py:197-202 only iterates over the dict's items) */
@@ -254,6 +254,18 @@ int ccx_rollout(ccx_handle* h, int32_t num_steps, const uint8_t* actions, const 
  */
 int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t auto_reset,
                        const ccx_rollout_out* out, uint8_t* actions_out);
+/*
+ * CCX_POLICY_RANDOM: uniform random actions drawn on the device -- the random-action rollouts of the
+ * reference's tests and demos (e.g. tests/.../test_trajectory_vcr.py) without an action tensor (SURVEY 8b:
+ * `rng_seed` of ccx_rollout).  The action of agent slot a of global env g at step t (0-based) of its episode j is
+ *     k = g*0x9E3779B1 + j*0x85EBCA77 + t*0xC2B2AE3D + a*0x27D4EB2F + seed_lo        (u32 arithmetic)
+ *     k = mix(k);  k ^= seed_hi;  k = mix(k);       mix: k^=k>>16; k*=0x7FEB352D; k^=k>>15; k*=0x846CA68B; k^=k>>16
+ *     action = (k * 5) >> 32
+ * for every agent of env.agents (others: CCX_ACTION_ABSENT in actions_out).  It depends on the env's own
+ * counters only, so the stream of an env is the same for any split into launches and any world size.  This is
+ * NOT numpy's stream: trajectories driven by it are pinned by the oracle's restatement of the same function.
+ */
+int ccx_set_rng_seed(ccx_handle* h, uint64_t seed);
 
 /*
  * Opt-in input validation for the array API (the dict API validates on the host).  The reference raises

@@ -76,6 +76,8 @@ def lib() -> C.CDLL:
         L.ccxo_rollout_policy.restype = None
         L.ccxo_policy_actions.argtypes = [PP, C.c_int32, C.c_int32] + [V] * 6
         L.ccxo_policy_actions.restype = None
+        L.ccxo_set_rng_seed.argtypes = [C.c_uint64]
+        L.ccxo_set_rng_seed.restype = None
         L.ccxo_greedy_actions.argtypes = [PP, C.c_int32] + [V] * 6
         L.ccxo_greedy_actions.restype = None
         _lib = L
@@ -172,7 +174,12 @@ class OracleBatch:
                            _p(self.active, np.uint8), _p(obs, np.float32))
         return obs
 
-    POLICIES = {"greedy": 1, "waiting": 2}
+    POLICIES = {"greedy": 1, "waiting": 2, "random": 3}
+
+    @staticmethod
+    def set_rng_seed(seed: int) -> None:
+        """Seed of CCX_POLICY_RANDOM (process-wide in the oracle)."""
+        lib().ccxo_set_rng_seed(C.c_uint64(int(seed) & (2**64 - 1)))
 
     def policy_actions(self, policy: str = "greedy") -> np.ndarray:
         """Epsilon-0 GreedyPolicy / WaitingPolicy action of every live agent, u8 [E, N]."""

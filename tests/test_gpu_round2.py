@@ -340,3 +340,30 @@ def test_a_paced_rollout_captured_into_a_graph_replays_without_touching_the_cont
     assert after["next_pace_ns"] == before["next_pace_ns"] and after["calm_launches"] == before["calm_launches"]
     assert env.counters()["env_steps"] == (3 + 5) * K * E
     env.close()
+
+
+# ---- CCX_POLICY_RANDOM: uniform actions drawn on the device ------------------------------------------
+@pytest.mark.parametrize("cfg_name,E,K", [("g8_rollout_c1", 777, 130), ("g3_c3_dense_simple_distance", 150, 60),
+                                          ("g7_n5_odd", 200, 90), ("g4_c5_all_at_dest_greedy_32_32", 40, 70)])
+def test_device_random_rollout_equals_the_oracle(oracle, ccx, cfg_name, E, K):
+    from collectivecrossing_amd.reset import build_reset_pool
+    g = Golden(cfg_name)
+    pool = build_reset_pool(g.config, 77, 129)
+    seed = 0xDEADBEEF12345678 ^ E
+    oracle.OracleBatch.set_rng_seed(seed)
+    ob = oracle.OracleBatch(g.params, E, env_offset=5, total_envs=E + 9)
+    env = ccx(g.config, E, env_offset=5, total_envs=E + 9)
+    env.set_rng_seed(seed)
+    for b in (ob, env):
+        b.set_reset_pool(pool)
+        b.reset_from_pool()
+    o_act, o_obs, o_rew, o_af, o_ef = ob.rollout_greedy(K, auto_reset=True, policy="random")
+    res, acts = env.rollout_policy(K // 2, "random", auto_reset=True)          # two launches: same stream
+    res2, acts2 = env.rollout_policy(K - K // 2, "random", auto_reset=True)
+    np.testing.assert_array_equal(np.concatenate([_np(acts), _np(acts2)]), o_act)
+    np.testing.assert_array_equal(np.concatenate([_np(res.obs), _np(res2.obs)]).view(np.uint32), o_obs.view(np.uint32))
+    np.testing.assert_array_equal(np.concatenate([_np(res.reward), _np(res2.reward)]).view(np.uint64), o_rew.view(np.uint64))
+    np.testing.assert_array_equal(np.concatenate([_np(res.agent_flags), _np(res2.agent_flags)]), o_af)
+    np.testing.assert_array_equal(np.concatenate([_np(res.env_flags), _np(res2.env_flags)]), o_ef)
+    assert env.counters() == ob.counters.as_dict() and ob.counters.moves > 0
+    env.close()

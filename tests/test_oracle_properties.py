@@ -93,3 +93,38 @@ def test_two_identical_runs_are_identical(oracle):
         outs.append(b.rollout(g["actions"], g["order"]))
     for a, c in zip(*outs):
         np.testing.assert_array_equal(a, c)
+
+
+def test_device_random_policy_stream_is_uniform_and_independent_of_splits(oracle):
+    """CCX_POLICY_RANDOM (include/ccx.h: ccx_set_rng_seed): a counter-based hash of (seed, global env, episode,
+    step of the episode, agent).  Restated in the oracle; properties: all five actions ~uniform, a different
+    seed gives a different stream, and an env's stream does not depend on how the batch is cut into shards or
+    the rollout into launches."""
+    from _fixtures import Golden
+
+    from collectivecrossing_amd.reset import build_reset_pool
+    g = Golden("g8_rollout_c1")
+    pool = build_reset_pool(g.config, 40, 61)
+
+    def run(E, K_parts, off=0, total=24, seed=1234):
+        oracle.OracleBatch.set_rng_seed(seed)
+        b = oracle.OracleBatch(g.params, E, env_offset=off, total_envs=total)
+        b.set_reset_pool(pool)
+        b.reset_from_pool()
+        outs = [b.rollout_greedy(k, auto_reset=True, policy="random") for k in K_parts]
+        return [np.concatenate([o[j] for o in outs], axis=0) for j in range(5)], b
+
+    (acts, obs, rew, af, ef), b = run(24, [120])
+    live = acts != 255
+    counts = np.bincount(acts[live], minlength=5)
+    assert counts.min() > 0.17 * live.sum() and counts.max() < 0.23 * live.sum() and set(np.unique(acts)) <= {0, 1, 2, 3, 4, 255}
+    assert b.counters.episodes > 24        # the stream goes on across auto-resets (episode is part of the key)
+    (acts2, obs2, *_), _ = run(24, [50, 70])                      # two launches
+    np.testing.assert_array_equal(acts, acts2)
+    np.testing.assert_array_equal(obs.view(np.uint32), obs2.view(np.uint32))
+    (a_lo, o_lo, *_), _ = run(10, [120], off=0)                   # two shards of the same global batch
+    (a_hi, o_hi, *_), _ = run(14, [120], off=10)
+    np.testing.assert_array_equal(np.concatenate([a_lo, a_hi], axis=1), acts)
+    np.testing.assert_array_equal(np.concatenate([o_lo, o_hi], axis=1).view(np.uint32), obs.view(np.uint32))
+    (acts3, *_), _ = run(24, [120], seed=1235)
+    assert (acts3 != acts).mean() > 0.5
