@@ -204,7 +204,8 @@ class VectorCollectiveCrossing:
         o = np.empty((E, N), np.uint8)
         for e, d in enumerate(action_dicts):
             a[e], o[e] = encode_actions(self.agent_ids, d)
-        out = self.step(a, o)
+        # every dict in slot order (the usual `{a: ... for a in env.agents}`): no move-order tensor, plain kernel path
+        out = self.step(a, None if bool((o == np.arange(N, dtype=np.uint8)).all()) else o)
         if auto_reset:
             self._pull()
             done = (self._h_ef & (_abi.EF_ALL_TERMINATED | _abi.EF_ALL_TRUNCATED)) != 0

@@ -509,8 +509,8 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
               suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much, HealthCheck.function_scoped_fixture])
     @given(cfg=st.one_of(configs(), configs(max_boarding=25, max_exiting=25)), seed=st.integers(0, 2**20),
            E=st.sampled_from([1, 5, 64, 130, 257]), K=st.integers(1, 48),
-           mode=st.sampled_from(["actions", "actions", "greedy", "waiting"]))
-    def run(cfg, seed, E, K, mode):
+           mode=st.sampled_from(["actions", "actions", "greedy", "waiting", "random"]), compact=st.booleans())
+    def run(cfg, seed, E, K, mode, compact):
         p = lower_config(cfg)
         N = p.num_boarding + p.num_exiting
         rng = np.random.default_rng(seed)
@@ -523,16 +523,22 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
             for b in (ob, env):
                 b.set_reset_pool(pool)
                 b.reset_from_pool()
+            # compact: the rollout writes only the [E][N][4] observation rows; they are expanded afterwards
+            out = env.alloc_rollout(K, want_obs=not compact, want_compact=compact)
             if mode == "actions":
                 o_obs, o_rew, o_af, o_ef = ob.rollout(actions, order, auto_reset=True)
-                res = env.rollout(actions, order, auto_reset=True)
-            else:       # the scripted policies evaluated inside the kernel
+                res = env.rollout(actions, order, auto_reset=True, out=out)
+            else:       # the scripted policies / the device RNG evaluated inside the kernel
+                if mode == "random":
+                    oracle.OracleBatch.set_rng_seed(seed * 2654435761 + 7)
+                    env.set_rng_seed(seed * 2654435761 + 7)
                 o_act, o_obs, o_rew, o_af, o_ef = ob.rollout_greedy(K, auto_reset=True, policy=mode)
-                res, acts = env.rollout_greedy(K, auto_reset=True, policy=mode)
+                res, acts = env.rollout_greedy(K, auto_reset=True, policy=mode, out=out)
                 np.testing.assert_array_equal(_np(acts), o_act)
             np.testing.assert_array_equal(_np(res.agent_flags), o_af)
             np.testing.assert_array_equal(_np(res.env_flags), o_ef)
-            np.testing.assert_array_equal(_np(res.obs).view(np.uint32), o_obs.view(np.uint32))
+            got_obs = _np(env.expand_observations(res.obs_compact)) if compact else _np(res.obs)
+            np.testing.assert_array_equal(got_obs.view(np.uint32), o_obs.view(np.uint32))
             np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64))
             assert env.counters() == ob.counters.as_dict()
         finally:
