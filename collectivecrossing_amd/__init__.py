@@ -1,14 +1,15 @@
 """collectivecrossing_amd -- MI355X-native batched CollectiveCrossing step.
 
-``CollectiveCrossingEnv`` (dict API, drop-in for the reference) and ``BatchedCollectiveCrossing``
-(array API) both run the step on the GPU through libccx (``include/ccx.h``); there is no CPU
-implementation of the step path in this package.
+``CollectiveCrossingEnv`` (dict API, drop-in for the reference), ``BatchedCollectiveCrossing``
+(array API) and ``VectorCollectiveCrossing`` (many envs behind per-env dict views) all run the step on
+the GPU through libccx (``include/ccx.h``); there is no CPU implementation of the step path in this
+package.
 """
 
 from .configs import CollectiveCrossingConfig  # noqa: F401
 
-__version__ = "0.1.0"
-__all__ = ["CollectiveCrossingConfig", "CollectiveCrossingEnv", "BatchedCollectiveCrossing"]
+__version__ = "0.3.0"
+__all__ = ["CollectiveCrossingConfig", "CollectiveCrossingEnv", "BatchedCollectiveCrossing", "VectorCollectiveCrossing"]
 
 
 def __getattr__(name):  # lazy: importing the configs must not pull in torch
@@ -18,6 +19,9 @@ def __getattr__(name):  # lazy: importing the configs must not pull in torch
     if name == "BatchedCollectiveCrossing":
         from .batched import BatchedCollectiveCrossing
         return BatchedCollectiveCrossing
+    if name == "VectorCollectiveCrossing":
+        from .vector import VectorCollectiveCrossing
+        return VectorCollectiveCrossing
     raise AttributeError(name)
 
 

@@ -223,6 +223,7 @@ int choose_shape(ccx_handle* h) {
     k.occ_words = s.occ ? (uint32_t)(occ_bytes / 4u) : 0u;
     k.off_table = (uint32_t)(off_tiles + (size_t)tpb * tile_stride);
     k.writer_vmcnt = (uint32_t)s.store_throttle;
+    k.writer0_small = (small_batch && writers >= 2) ? 1u : 0u;
 
     // Step pacing (ccx_kernels.hip).  The schedule limits the rate at which the resident
     // workgroups inject observation stores; its start value assumes a drain rate of 6.8 TB/s and the

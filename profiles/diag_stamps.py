@@ -20,7 +20,7 @@ from collectivecrossing_amd.reset import build_reset_pool  # noqa: E402
 
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 writers = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-E, K, N = 4096, 256, 8
+E, K, N = (int(sys.argv[3]) if len(sys.argv) > 3 else 4096), 256, 8
 cfg = c2_config()
 env = BatchedCollectiveCrossing(cfg, E)
 env.set_timing(True)
