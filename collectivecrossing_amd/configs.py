@@ -224,6 +224,10 @@ class CollectiveCrossingConfig(ConfigClass):
     reward_config: RewardConfig = Field(default_factory=DefaultRewardConfig)
     terminated_config: TerminatedConfig = Field(default_factory=IndividualAtDestinationTerminatedConfig)
     truncated_config: TruncatedConfig = Field(default_factory=MaxStepsTruncatedConfig)
+    # Not a field of the reference: its validator caps the total at min(w*h//4, 50) agents (configs.py:166), so
+    # BASELINE configs[4] (32 + 32 agents) cannot even be constructed there.  False lifts that one
+    # cap to the library's own limit of 64 agents per env (one wavefront lane per agent); every other rule stays.
+    strict_reference_limits: bool = True
 
     # ---- cross-field rules, one generator so get_validation_errors() can list them all -------
     def _violations(self):
@@ -253,7 +257,7 @@ class CollectiveCrossingConfig(ConfigClass):
                 yield "Environment bounds", (f"Tram door {side} boundary ({v}) must be less than "
                                              f"environment width ({w})")
         nb, ne = self.num_boarding_agents, self.num_exiting_agents
-        cap = min(w * h // 4, 50)
+        cap = min(w * h // 4, 50) if self.strict_reference_limits else min(w * h // 4, 64)
         if nb + ne > cap:
             yield "Agent count", (f"Total number of agents ({nb + ne}) exceeds reasonable limit "
                                   f"({cap}) for environment size {w}x{h}")

@@ -199,3 +199,25 @@ def test_host_placement_gives_up_where_the_reference_would_spin():
         render_mode=None)
     with _pytest.raises(RuntimeError, match="no free legal cell"):
         sample_initial_positions(cfg, make_generator(0))
+
+
+def test_strict_reference_limits_switch_lifts_only_the_total_agent_cap():
+    """SURVEY 8 a-12: the reference caps the total at min(w*h//4, 50) agents (configs.py:166); BASELINE configs[4]
+    needs 64.  `strict_reference_limits=False` lifts that one cap to the library's 64, nothing else."""
+    import pytest
+    from pydantic import ValidationError
+
+    from collectivecrossing_amd import configs as C
+    from collectivecrossing_amd.params import lower_config
+    kw = dict(width=32, height=16, division_y=8, tram_door_left=10, tram_door_right=16, tram_length=26,
+              exiting_destination_area_y=0, boarding_destination_area_y=16)
+    with pytest.raises(ValidationError, match="exceeds reasonable limit"):
+        C.CollectiveCrossingConfig(**kw, num_boarding_agents=32, num_exiting_agents=32)
+    cfg = C.CollectiveCrossingConfig(**kw, num_boarding_agents=32, num_exiting_agents=32, strict_reference_limits=False)
+    assert lower_config(cfg).num_agents == 64 and cfg.is_valid()
+    with pytest.raises(ValidationError, match="exceeds reasonable limit"):
+        C.CollectiveCrossingConfig(**kw, num_boarding_agents=33, num_exiting_agents=32, strict_reference_limits=False)
+    with pytest.raises(ValidationError, match="Tram length"):       # the other rules still hold
+        C.CollectiveCrossingConfig(**dict(kw, tram_length=40), num_boarding_agents=2, num_exiting_agents=2,
+                                   strict_reference_limits=False)
+    assert C.CollectiveCrossingConfig(**kw, num_boarding_agents=2, num_exiting_agents=2).strict_reference_limits is True
