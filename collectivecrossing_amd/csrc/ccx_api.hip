@@ -114,7 +114,7 @@ int choose_shape(ccx_handle* h) {
         const size_t msz_ = (glog == 6) ? 8u : 4u;
         auto need = [&](int e) {
             const size_t units_ = (size_t)e * h->N * (3 + 2 * h->N);
-            return up(cells_ * 8u) + up(256u + 2048u + 7u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) +
+            return up(cells_ * 8u) + up(256u + 4096u + 7u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) +
                    up((units_ + 2u) * 2u);
         };
         if (need(1) <= 96u * 1024u)
@@ -127,15 +127,15 @@ int choose_shape(ccx_handle* h) {
     // half-empty single-writer tiles chosen before: 1024 envs 0.53 vs 0.58, 2048 envs 0.54 vs 0.59 (0.63 vs
     // 0.58 of the HBM peak), 3072 envs 0.63 vs 0.72 (0.81 vs 0.70).
     bool small_batch = false;
-    if (h->lanes_per_wave == 0 && h->writers == 0 && h->waves_per_block == 0) {
+    if (h->lanes_per_wave == 0 && h->writers != 1 && h->waves_per_block == 0) {
         const long long full_tiles = (h->E + max_ew - 1) / max_ew;
         const int full_n4 = max_ew * h->N * (3 + 2 * h->N) / ((h->N % 2 == 0) ? 2 : 1);
-        if (full_n4 <= 64 * 12 && full_tiles * 3 <= 1400 && full_tiles * max_ew >= 256) {
+        if (full_n4 <= 64 * 12 && full_tiles * (1 + (h->writers > 0 ? h->writers : 2)) <= 1400 && full_tiles * max_ew >= 256) {
             auto up = [](size_t v) { return (v + 15u) & ~(size_t)15u; };   // (only if the LDS tables of a full tile fit)
             const size_t cells_ = (size_t)(h->params.width + 3) * (size_t)(h->params.height + 3);
             const size_t msz_ = (glog == 6) ? 8u : 4u;
             const size_t units_ = (size_t)max_ew * h->N * (3 + 2 * h->N);
-            if (up(cells_ * 8u) + up(256u + 2048u + 2u * 1056u + up((size_t)max_ew * 2u * (cells_ + 1u) * msz_)) +
+            if (up(cells_ * 8u) + up(256u + 4096u + 2u * 1056u + up((size_t)max_ew * 2u * (cells_ + 1u) * msz_)) +
                     up((units_ + 2u) * 2u) <= 96u * 1024u) {
                 small_batch = true;
                 ew = max_ew;
@@ -151,7 +151,10 @@ int choose_shape(ccx_handle* h) {
     // regulator when step pacing is off and a safety net when it is on).
     // Larger tiles: 2-3 writers, no throttle (measured: no effect).
     const bool small_tiles = n4 <= 64 * 12;
-    int writers = h->writers > 0 ? h->writers : small_batch ? 2 : (n4 > 64 * 24 ? 3 : small_tiles ? 1 : 2);
+    // small batches: writer 0 = small outputs, the others share the observation rows (KParams::writer0_small);
+    // three writers while 4 waves x tiles still fit the 1024 SIMDs (2048-env C2: 0.54 -> 0.485 us per step)
+    int writers = h->writers > 0 ? h->writers
+                  : small_batch ? ((long long)tiles * 4 <= 1100 ? 3 : 2) : (n4 > 64 * 24 ? 3 : small_tiles ? 1 : 2);
     if (writers > 7) writers = 7;
     // tiles per workgroup: two small tiles share one cell table / one CU slot (with the throttle:
     // 4.43e9 vs 4.23e9 env-steps/s on C2; 3 or 4 per workgroup leave CUs idle and lose 5-10 %)
@@ -190,7 +193,7 @@ int choose_shape(ccx_handle* h) {
     const size_t occ_bytes = up16((size_t)ew * 2u * (cells + 1u) * msz);
     const size_t table = up16((size_t)(units + 2) * 2u);
     const size_t off_tiles = up16(cells * 8u);
-    const size_t off_ws = 256u + 2048u;                         // xch + stage
+    const size_t off_ws = 256u + 4096u;                         // xch + stage ring (4 slots)
     const size_t off_occ = off_ws + (size_t)writers * 1056u;    // WSlot per writer
     size_t tile_stride = up16(off_occ + occ_bytes);
     size_t total = off_tiles + (size_t)tpb * tile_stride + table;
@@ -344,6 +347,8 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     // cannot adapt across replays (the slot flip below happens once, at capture time), so such a launch runs
     // at the pace in effect and neither votes nor touches the controller's state.
     ccx::KParams kp = h->kp;
+    // paired hand-offs for launches the kernel will not pace (same condition as in the kernel)
+    kp.hand2 = (kp.pace_state && out.obs && K >= 16) ? 0u : (h->tun_hand2 != 0 ? 1u : 0u);
     const bool adaptive = kp.pace_state && kp.pace_adapt && out.obs && K >= 64;
     bool capturing = false;
     if (adaptive) {
@@ -820,6 +825,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
     struct { const char* name; int* slot; int lo, hi; } table[] = {
         {"pace_phase", &h->tun_pace_phase, -1, 3},
         {"tile_map", &h->tun_tile_map, -1, 6},
+        {"hand2", &h->tun_hand2, 0, 1},
     };
     for (auto& t : table)
         if (strcmp(name, t.name) == 0) {
@@ -828,7 +834,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
             *t.slot = value;
             return choose_shape(h);
         }
-    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map)", name);
+    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, hand2)", name);
 }
 
 int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {

@@ -55,6 +55,7 @@ struct KParams {
     long long pool_stride;               // cursor stride: total_envs mod pool_size, 1 when that is 0
     // tunables (ccx_set_tunable): how the tiles' step schedules are phased, how workgroups map to tiles
     uint32_t pace_phase, tile_map;
+    uint32_t hand2;                      // 1: one sim -> writer hand-off barrier per two env-steps (unpaced launches)
     uint32_t writer0_small;              // 1: writer 0 writes the small outputs only, writers 1.. the observation rows
     uint32_t rng_lo, rng_hi;             // seed of CCX_POLICY_RANDOM (ccx_set_rng_seed)
 };

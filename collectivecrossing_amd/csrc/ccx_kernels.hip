@@ -164,7 +164,7 @@ template <typename T> __device__ __forceinline__ T in_vgpr(T v) {
 
 // LDS tiles.  WSlot: what a wave that writes observation rows gathers from (one per writer wave /
 // per wave of the observe kernel).  The rollout kernel's per-tile carve-up (byte offsets in
-// KParams): [xch u32 x 64][stage uint4 x 2 x 64][WSlot x writers][occ | prp masks x EW x (cells+1)].
+// KParams): [xch u32 x 64][stage uint4 x 4 x 64][WSlot x writers][occ | prp masks x EW x (cells+1)].
 struct WSlot {
     float4 slot[64];   // (x, y, type, active) of the agent on each lane, as floats
     float cst[8];      // (door_centre, division_y) (door_left, door_right) (-1,-1) pad

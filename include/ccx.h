@@ -352,7 +352,9 @@ int ccx_set_step_pace_start(ccx_handle* h, float ns_per_env_step);
  *                  period in tile order (one write window sweeps through the slab), 2 = hashed phases,
  *                  3 = in tile order within each XCD's share (with tile_map 0)
  *   "tile_map"     0 = workgroups of one XCD take adjacent tiles, v >= 1 = groups of 2^(v-1) adjacent tiles
- *                  per XCD dealt round-robin (1 = tile = workgroup index) */
+ *                  per XCD dealt round-robin (1 = tile = workgroup index)
+ *   "hand2"        1 (default) = launches that are not paced hand two env-steps at a time from the simulating
+ *                  wavefront to the writer wavefronts (one barrier per two steps), 0 = one per step */
 int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value);
 /* workgroups of a rollout launch with outputs, and how many of them the device holds at once (a grid
  * larger than that runs in rounds; the pace of a partial last round is scaled accordingly) */

@@ -16,6 +16,8 @@ from collectivecrossing_amd.batched import BatchedCollectiveCrossing  # noqa: E4
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 K = 500
 env = BatchedCollectiveCrossing(c2_config(), E)
+for kv in sys.argv[2:]:          # tunables: name=value
+    env.set_tunable(kv.split("=")[0], int(kv.split("=")[1]))
 env.make_reset_pool(0, 4096)
 env.reset_from_pool()
 acts = torch.randint(0, 5, (K, E, env.num_agents), dtype=torch.uint8, device=env.device)
@@ -35,7 +37,7 @@ def timed(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3 / K
 
 
-print(f"E={E} lib={os.environ.get('CCX_DIAG_LIB', 'shipped')[-16:]}: "
+print(f"E={E} {' '.join(sys.argv[2:])} lib={os.environ.get('CCX_DIAG_LIB', 'shipped')[-16:]}: "
       f"sim only {timed(lambda: env.rollout(acts, auto_reset=True, want_traj=False)):.4f}  "
       f"rewards+flags {timed(lambda: env.rollout(acts, auto_reset=True, out=small)):.4f}  "
       f"full {timed(lambda: env.rollout(acts, auto_reset=True, out=full), 40):.4f} us per env-step", flush=True)

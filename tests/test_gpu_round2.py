@@ -90,8 +90,9 @@ def test_full_size_c3_shuffled_orders_equal_the_oracle(oracle, ccx):
 
 
 @pytest.mark.parametrize("knobs", [{"pace_phase": 0, "tile_map": 0}, {"pace_phase": 1, "tile_map": 1}, {"pace_phase": 2, "tile_map": 4},
-                                   {"pace_phase": 3, "tile_map": 0}, {"pace_phase": 1, "tile_map": 6}])
-@pytest.mark.parametrize("cfg_name,E,K", [("g1_c1_random", 4096, 70), ("g3_c3_dense_simple_distance", 1500, 20)])
+                                   {"pace_phase": 3, "tile_map": 0}, {"pace_phase": 1, "tile_map": 6}, {"hand2": 0}])
+@pytest.mark.parametrize("cfg_name,E,K", [("g1_c1_random", 4096, 70), ("g3_c3_dense_simple_distance", 1500, 20),
+                                          ("g1_c1_random", 700, 33)])
 def test_tunables_never_change_results(oracle, ccx, cfg_name, E, K, knobs):
     def setup(env):
         for k, v in knobs.items():
@@ -277,7 +278,9 @@ def test_compact_rollout_with_autoreset_and_policy_equals_the_full_rollout(ccx):
 def test_steady_state_launches_have_no_outliers(ccx):
     """The adaptive pace controller in steady state: after the start-up phase, 60 consecutive
     C2 launches (4096 envs x 8 agents, 500 env-steps each, full outputs) stay within a few per cent of their
-    median -- a collapse of the drain rate costs ~8 % of a launch and must be a rare event, not a rhythm."""
+    median -- a collapse of the drain rate costs ~8 % of a launch and must be a rare event, not a rhythm (round 1:
+    one every 15-20 launches).  Bounds with room for the lease-to-lease spread: at most two launches above 1.05 x
+    the median, none above 1.10 x."""
     import torch
 
     from bench import c2_config
@@ -300,16 +303,16 @@ def test_steady_state_launches_have_no_outliers(ccx):
     st = env.pace_state()
     env.close()
     assert st["paced"] == 1.0 and st["next_pace_ns"] > 0
-    assert over <= 1 and ms.max() < 1.15 * med, (over, ms.max() / med, sorted(ms)[-3:], st)
+    assert over <= 2 and ms.max() < 1.10 * med, (over, ms.max() / med, sorted(ms)[-3:], st)
 
 
 @pytest.mark.parametrize("E", [1024, 2048, 3072])
 def test_small_batches_use_full_tiles_with_two_writers_and_equal_the_oracle(oracle, ccx, E):
-    """Below the memory-bound regime the default shape is full 64-lane tiles with two writer waves each
-    (DESIGN.md 4): same results, of course."""
+    """Below the memory-bound regime the default shape is full 64-lane tiles with two or three writer waves each,
+    split by role: same results, of course."""
     g = Golden("g8_rollout_c1")
     c, shape, _, _ = _against_oracle(oracle, ccx, g, E=E, K=70, seed=17 + E)
-    assert (shape["lanes_per_wave"], shape["writers_per_tile"], shape["waves_per_block"]) == (64, 2, 1)
+    assert (shape["lanes_per_wave"], shape["writers_per_tile"], shape["waves_per_block"]) == (64, 3 if E <= 2048 else 2, 1)
     assert c["episodes"] > 0
 
 
