@@ -153,8 +153,16 @@ int choose_shape(ccx_handle* h) {
     const bool small_tiles = n4 <= 64 * 12;
     // small batches: writer 0 = small outputs, the others share the observation rows (KParams::writer0_small);
     // three writers while 4 waves x tiles still fit the 1024 SIMDs (2048-env C2: 0.54 -> 0.485 us per step)
+    // Small tiles beyond that (C2's 4096 x 8: 9.5 store iterations per tile and step): TWO writers split by role
+    // as well, as long as 3 waves per tile fit one round (16 wavefronts per CU).  With everything on one writer
+    // that wave had 1580 clocks of work per step next to the sim's 1200 and held the tile at ~0.72 us per step --
+    // C2 was bound by its writer wave, not by memory; with two the pace follows the memory side down to
+    // ~0.70 us: 0.86 -> 0.92 of the HBM peak in one call (round 2; round 1 measured two writers as no gain,
+    // but its sim wave was 20 % slower and hid the difference).
     int writers = h->writers > 0 ? h->writers
-                  : small_batch ? ((long long)tiles * 4 <= 1100 ? 3 : 2) : (n4 > 64 * 24 ? 3 : small_tiles ? 1 : 2);
+                  : small_batch ? ((long long)tiles * 4 <= 1100 ? 3 : 2)
+                  : n4 > 64 * 24 ? 3
+                  : small_tiles ? ((long long)tiles * 3 <= 16ll * h->num_cus ? 2 : 1) : 2;
     if (writers > 7) writers = 7;
     // tiles per workgroup: two small tiles share one cell table / one CU slot (with the throttle:
     // 4.43e9 vs 4.23e9 env-steps/s on C2; 3 or 4 per workgroup leave CUs idle and lose 5-10 %)
@@ -226,7 +234,7 @@ int choose_shape(ccx_handle* h) {
     k.occ_words = s.occ ? (uint32_t)(occ_bytes / 4u) : 0u;
     k.off_table = (uint32_t)(off_tiles + (size_t)tpb * tile_stride);
     k.writer_vmcnt = (uint32_t)s.store_throttle;
-    k.writer0_small = (small_batch && writers >= 2) ? 1u : 0u;
+    k.writer0_small = (h->tun_writer_roles >= 0 ? h->tun_writer_roles != 0 : (small_batch || small_tiles)) && writers >= 2 ? 1u : 0u;
 
     // Step pacing (ccx_kernels.hip).  The schedule limits the rate at which the resident
     // workgroups inject observation stores; its start value assumes a drain rate of 6.8 TB/s and the
@@ -826,6 +834,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
         {"pace_phase", &h->tun_pace_phase, -1, 3},
         {"tile_map", &h->tun_tile_map, -1, 6},
         {"hand2", &h->tun_hand2, 0, 1},
+        {"writer_roles", &h->tun_writer_roles, -1, 1},
     };
     for (auto& t : table)
         if (strcmp(name, t.name) == 0) {
@@ -834,7 +843,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
             *t.slot = value;
             return choose_shape(h);
         }
-    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, hand2)", name);
+    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, hand2, writer_roles)", name);
 }
 
 int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {

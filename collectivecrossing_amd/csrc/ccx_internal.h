@@ -51,6 +51,7 @@ struct ccx_handle {
     int num_cus = 256;
     float pace_start_ns = 0.0f;                                // > 0: the adaptive controller starts here (ccx_set_step_pace_start)
     int tun_pace_phase = -1, tun_tile_map = -1;                 // -1 = the library's choice for the launch shape
+    int tun_writer_roles = -1;                                  // -1 = by batch size, 0 = writers share everything, 1 = writer 0 small outputs only
     int tun_hand2 = 1;                                          // paired hand-offs in unpaced launches
     bool check_inputs = false;                                 // ccx_set_check_inputs
     unsigned long long* input_errors = nullptr;                // device [2]: bad action bytes, bad order rows

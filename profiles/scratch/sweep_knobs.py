@@ -31,6 +31,8 @@ for w in workloads:
             for k, v in combo.items():
                 if k == "writers":
                     env.set_writers(v)
+                elif k == "throttle":
+                    env.set_store_throttle(v)
                 elif k == "pace":
                     env.set_step_pace(v)
                 elif k == "lanes":
