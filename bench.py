@@ -295,6 +295,9 @@ def parse_args(argv=None):
                     help="random = actions from a device tensor (the bench line); greedy = the "
                          "reference's GreedyPolicy(epsilon=0) evaluated inside the rollout kernel (BASELINE configs[4]); "
                          "device-random = uniform actions drawn inside the kernel (CCX_POLICY_RANDOM), no action tensor")
+    ap.add_argument("--epsilon", type=float, default=0.0,
+                    help="with --policy greedy: the policy's randomness_factor, drawn on the device "
+                         "(ccx_set_policy_epsilon; the reference's create_greedy_policy default is 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the no-obs / K=1 secondary figures")
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip the observation output")
@@ -382,6 +385,9 @@ def run_rank(args) -> int:
         env.set_store_throttle(args.throttle)
     if args.pace:
         env.set_step_pace(args.pace)
+    if args.epsilon:
+        env.set_rng_seed(1234 + rank)
+        env.set_policy_epsilon(args.epsilon)
     env.make_reset_pool(0, args.pool, on_device=not os.environ.get("CCX_DIAG_LIB"))  # seeds 0..pool-1
     env.reset_from_pool()
 
@@ -491,7 +497,7 @@ def run_rank(args) -> int:
                                     "max_steps=100, uniform random actions, auto-reset from "
                                     f"{args.pool} reference-exact seeded placements") if args.workload == "c2"
                        else f"{args.workload} (diagnostic, not the bench line)",
-                       "policy": args.policy,
+                       "policy": args.policy if not args.epsilon else f"{args.policy}, epsilon {args.epsilon} (device draws)",
                        "envs_per_gpu": E, "global_envs": total, "agents": N, "obs_len": L,
                        "step": "one fused rollout launch over an action batch [env_steps_per_step, envs, agents]",
                        "env_steps_per_step": chunk, "steps_per_launch": chunk,

@@ -325,6 +325,13 @@ class BatchedCollectiveCrossing:
         """Seed of the on-device action RNG (``CCX_POLICY_RANDOM``)."""
         check(self._lib.ccx_set_rng_seed(self._h, int(seed) & (2**64 - 1)))
 
+    def set_policy_epsilon(self, epsilon: float) -> None:
+        """``randomness_factor`` of the on-device greedy / waiting policies (``ccx_set_policy_epsilon``): with
+        probability epsilon an agent takes one of its valid actions uniformly (the reference's
+        ``create_greedy_policy(epsilon=0.1)``), drawn from the counter-based RNG seeded by :meth:`set_rng_seed`
+        -- not numpy's stream; the host classes in ``baseline_policies`` keep that one.  0 = deterministic."""
+        check(self._lib.ccx_set_policy_epsilon(self._h, float(epsilon)))
+
     # ------------------------------------------------------------------ counters / timing / shape
     def zero_counters(self) -> None:
         check(self._lib.ccx_zero_counters(self._h))

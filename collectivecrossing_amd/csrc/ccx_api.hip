@@ -745,6 +745,14 @@ int ccx_set_rng_seed(ccx_handle* h, uint64_t seed) {
     return CCX_OK;
 }
 
+int ccx_set_policy_epsilon(ccx_handle* h, double epsilon) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if (!(epsilon >= 0.0 && epsilon <= 1.0)) return fail(CCX_EINVAL, "epsilon must be in [0, 1] (got %g)", epsilon);
+    const double t = epsilon * 4294967296.0;
+    h->kp.eps_thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    return CCX_OK;
+}
+
 int ccx_zero_counters(ccx_handle* h) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");
     CCX_HIP(hipSetDevice(h->device));

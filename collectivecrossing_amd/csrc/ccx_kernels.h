@@ -11,15 +11,43 @@ enum : int { CCX_K_REWARD_DEFAULT = 0, CCX_K_REWARD_SIMPLE_DISTANCE = 1, CCX_K_R
 enum : int { CCX_K_TERM_INDIVIDUAL = 0, CCX_K_TERM_ALL = 1 };
 enum : int { CCX_K_POLICY_GREEDY = 1, CCX_K_POLICY_WAITING = 2, CCX_K_POLICY_RANDOM = 3 };
 
-// CCX_POLICY_RANDOM: the action of agent `agent` of global env `genv` at step `step` (0-based) of its episode
-// `episode` -- a counter-based hash (lowbias32 rounds), uniform over 0..4 up to 2^-32; identical in the oracle
+// Counter-based random word of agent `agent` of global env `genv` at step `step` (0-based) of its episode
+// `episode` (lowbias32 rounds, restated by the CPU checker).  CCX_POLICY_RANDOM: action = word * 5 >> 32, uniform
+// over 0..4 up to 2^-32.
+__host__ __device__ inline uint32_t mix32(uint32_t k) {
+    k ^= k >> 16; k *= 0x7FEB352Du; k ^= k >> 15; k *= 0x846CA68Bu; k ^= k >> 16;
+    return k;
+}
+__host__ __device__ inline uint32_t random_word(uint32_t seed_lo, uint32_t seed_hi, uint32_t genv, uint32_t episode,
+                                                uint32_t step, uint32_t agent) {
+    uint32_t k = genv * 0x9E3779B1u + episode * 0x85EBCA77u + step * 0xC2B2AE3Du + agent * 0x27D4EB2Fu + seed_lo;
+    return mix32(mix32(k) ^ seed_hi);
+}
 __host__ __device__ inline uint32_t random_action(uint32_t seed_lo, uint32_t seed_hi, uint32_t genv, uint32_t episode,
                                                   uint32_t step, uint32_t agent) {
-    uint32_t k = genv * 0x9E3779B1u + episode * 0x85EBCA77u + step * 0xC2B2AE3Du + agent * 0x27D4EB2Fu + seed_lo;
-    k ^= k >> 16; k *= 0x7FEB352Du; k ^= k >> 15; k *= 0x846CA68Bu; k ^= k >> 16;
-    k ^= seed_hi;
-    k ^= k >> 16; k *= 0x7FEB352Du; k ^= k >> 15; k *= 0x846CA68Bu; k ^= k >> 16;
-    return (uint32_t)(((unsigned long long)k * 5ull) >> 32);
+    return (uint32_t)(((unsigned long long)random_word(seed_lo, seed_hi, genv, episode, step, agent) * 5ull) >> 32);
+}
+// Epsilon-greedy (greedy_policy.py:48-59, waiting_policy.py:48-59): the reference draws random() < epsilon and
+// then choice(valid_actions) from ONE RandomState shared by all agents of an env (a sequential stream); here the
+// two draws come from the agent's own counter-based word u (seed_hi ^ kEpsStream): explore iff u < epsilon * 2^32,
+// and the exploring action is the k-th (ascending) of the valid actions -- the free directions plus wait --
+// with k = mix32(u + 0x9E3779B9) * count >> 32.
+enum : uint32_t { kEpsStream = 0x5BD1E995u };
+__host__ __device__ inline uint32_t explore_action(uint32_t u, uint32_t free_dirs) {
+    uint32_t vm = (free_dirs & 0xFu) | 0x10u;          // wait is always valid (greedy_policy.py:251)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t count = (uint32_t)__popc(vm);
+#else
+    const uint32_t count = (uint32_t)__builtin_popcount(vm);
+#endif
+    const uint32_t k = (uint32_t)(((unsigned long long)mix32(u + 0x9E3779B9u) * count) >> 32);
+    for (uint32_t j = 0; j < 4u; ++j)
+        if (j < k) vm &= vm - 1u;                       // drop the k lowest valid actions
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(__ffs((int)vm) - 1);
+#else
+    return (uint32_t)__builtin_ctz(vm);
+#endif
 }
 enum : uint32_t { CCX_K_EF_ALL_TERM = 1u, CCX_K_EF_ALL_TRUNC = 2u, CCX_K_EF_RESET = 4u };
 
@@ -57,7 +85,8 @@ struct KParams {
     uint32_t pace_phase, tile_map;
     uint32_t hand2;                      // 1: one sim -> writer hand-off barrier per two env-steps (unpaced launches)
     uint32_t writer0_small;              // 1: writer 0 writes the small outputs only, writers 1.. the observation rows
-    uint32_t rng_lo, rng_hi;             // seed of CCX_POLICY_RANDOM (ccx_set_rng_seed)
+    uint32_t rng_lo, rng_hi;             // seed of CCX_POLICY_RANDOM and of the epsilon draws (ccx_set_rng_seed)
+    uint32_t eps_thr;                    // epsilon * 2^32 of the scripted policies (ccx_set_policy_epsilon), 0 = greedy
 };
 
 struct KState {

@@ -78,6 +78,8 @@ def lib() -> C.CDLL:
         L.ccxo_policy_actions.restype = None
         L.ccxo_set_rng_seed.argtypes = [C.c_uint64]
         L.ccxo_set_rng_seed.restype = None
+        L.ccxo_set_policy_epsilon.argtypes = [C.c_double]
+        L.ccxo_set_policy_epsilon.restype = None
         L.ccxo_greedy_actions.argtypes = [PP, C.c_int32] + [V] * 6
         L.ccxo_greedy_actions.restype = None
         _lib = L
@@ -180,6 +182,11 @@ class OracleBatch:
     def set_rng_seed(seed: int) -> None:
         """Seed of CCX_POLICY_RANDOM (process-wide in the oracle)."""
         lib().ccxo_set_rng_seed(C.c_uint64(int(seed) & (2**64 - 1)))
+
+    @staticmethod
+    def set_policy_epsilon(epsilon: float) -> None:
+        """randomness_factor of the greedy / waiting policies in rollout_greedy (process-wide in the oracle)."""
+        lib().ccxo_set_policy_epsilon(C.c_double(float(epsilon)))
 
     def policy_actions(self, policy: str = "greedy") -> np.ndarray:
         """Epsilon-0 GreedyPolicy / WaitingPolicy action of every live agent, u8 [E, N]."""

@@ -9,6 +9,11 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import os  # noqa: E402
+
+if os.environ.get("CCX_DIAG_LIB"):   # an experimental build (make variant NAME=...)
+    from collectivecrossing_amd import _lib
+    _lib.LIB_PATH = Path(os.environ["CCX_DIAG_LIB"]).resolve()
 from bench import rollout_bytes_per_agent_step, workload_config  # noqa: E402
 from collectivecrossing_amd.batched import BatchedCollectiveCrossing  # noqa: E402
 

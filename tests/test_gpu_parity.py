@@ -509,8 +509,10 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
               suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much, HealthCheck.function_scoped_fixture])
     @given(cfg=st.one_of(configs(), configs(max_boarding=25, max_exiting=25)), seed=st.integers(0, 2**20),
            E=st.sampled_from([1, 5, 64, 130, 257]), K=st.integers(1, 48),
-           mode=st.sampled_from(["actions", "actions", "greedy", "waiting", "random"]), compact=st.booleans())
-    def run(cfg, seed, E, K, mode, compact):
+           mode=st.sampled_from(["actions", "actions", "greedy", "waiting", "random"]), compact=st.booleans(),
+           writers=st.sampled_from([0, 0, 1, 2, 3, 4]), roles=st.sampled_from([-1, -1, 0, 1]),
+           hand2=st.sampled_from([1, 1, 0]), full_tiles=st.booleans(), eps=st.sampled_from([0.0, 0.0, 0.1, 0.5, 1.0]))
+    def run(cfg, seed, E, K, mode, compact, writers, roles, hand2, full_tiles, eps):
         p = lower_config(cfg)
         N = p.num_boarding + p.num_exiting
         rng = np.random.default_rng(seed)
@@ -520,6 +522,16 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
         pool = build_reset_pool(cfg, seed % 977, 37)
         ob, env = oracle.OracleBatch(p, E), ccx(cfg, E)
         try:
+            # launch shape: writer waves per tile, their role split, paired hand-offs, 64-lane tiles
+            if writers:
+                env.set_writers(writers)
+            env.set_tunable("writer_roles", roles)
+            env.set_tunable("hand2", hand2)
+            if full_tiles and mode in ("actions", "random"):   # (the scripted policies need the LDS occupancy tables)
+                try:
+                    env.set_launch_shape(64, 0)
+                except Exception:          # a grid whose tables for 64 lanes of envs exceed the LDS: the library's shape
+                    env.set_launch_shape(0, 0)
             for b in (ob, env):
                 b.set_reset_pool(pool)
                 b.reset_from_pool()
@@ -529,9 +541,10 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
                 o_obs, o_rew, o_af, o_ef = ob.rollout(actions, order, auto_reset=True)
                 res = env.rollout(actions, order, auto_reset=True, out=out)
             else:       # the scripted policies / the device RNG evaluated inside the kernel
-                if mode == "random":
-                    oracle.OracleBatch.set_rng_seed(seed * 2654435761 + 7)
-                    env.set_rng_seed(seed * 2654435761 + 7)
+                oracle.OracleBatch.set_rng_seed(seed * 2654435761 + 7)
+                env.set_rng_seed(seed * 2654435761 + 7)
+                oracle.OracleBatch.set_policy_epsilon(eps)      # epsilon-greedy / -waiting (no effect on "random")
+                env.set_policy_epsilon(eps)
                 o_act, o_obs, o_rew, o_af, o_ef = ob.rollout_greedy(K, auto_reset=True, policy=mode)
                 res, acts = env.rollout_greedy(K, auto_reset=True, policy=mode, out=out)
                 np.testing.assert_array_equal(_np(acts), o_act)
@@ -542,9 +555,67 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
             np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64))
             assert env.counters() == ob.counters.as_dict()
         finally:
+            oracle.OracleBatch.set_policy_epsilon(0.0)
             env.close()
 
     run()
+
+
+@pytest.mark.parametrize("name,E,K,policy,eps", [
+    ("g4_c5_all_at_dest_greedy_25_25", 96, 130, "greedy", 0.1), ("g4_c5_all_at_dest_greedy_32_32", 64, 100, "greedy", 0.1),
+    ("g4_c5_all_at_dest_greedy_32_32", 33, 70, "waiting", 0.5), ("g8_rollout_c1", 700, 150, "greedy", 1.0),
+    ("g9_c1_waiting_policy", 300, 120, "waiting", 0.1)])
+def test_epsilon_greedy_rollouts_equal_the_oracle(oracle, ccx, name, E, K, policy, eps):
+    """ccx_set_policy_epsilon: the reference's create_greedy_policy(epsilon=0.1) / create_waiting_policy shape
+    of rollout with the draws on the device (counter-based, include/ccx.h) -- actions, observations, rewards,
+    flags and counters bit-equal to the oracle's restatement, across auto-resets and two launches."""
+    from collectivecrossing_amd.reset import build_reset_pool
+
+    g = Golden(name)
+    pool = build_reset_pool(g.config, 11, 200)
+    ob, env = oracle.OracleBatch(g.params, E), ccx(g.config, E)
+    try:
+        for b in (ob, env):
+            b.set_reset_pool(pool)
+            b.reset_from_pool()
+        oracle.OracleBatch.set_rng_seed(2024)
+        oracle.OracleBatch.set_policy_epsilon(eps)
+        env.set_rng_seed(2024)
+        env.set_policy_epsilon(eps)
+        first_acts = None
+        for part in (K // 2, K - K // 2):
+            o_act, o_obs, o_rew, o_af, o_ef = ob.rollout_greedy(part, auto_reset=True, policy=policy)
+            res, acts = env.rollout_greedy(part, auto_reset=True, policy=policy)
+            np.testing.assert_array_equal(_np(acts), o_act)
+            np.testing.assert_array_equal(_np(res.agent_flags), o_af)
+            np.testing.assert_array_equal(_np(res.env_flags), o_ef)
+            np.testing.assert_array_equal(_np(res.obs).view(np.uint32), o_obs.view(np.uint32))
+            np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64))
+            first_acts = o_act if first_acts is None else first_acts
+            del res
+        assert env.counters() == ob.counters.as_dict()
+        assert ob.counters.episodes > 0
+        # the draws did change the rollout: the epsilon-0 policy takes other actions from the same start
+        oracle.OracleBatch.set_policy_epsilon(0.0)
+        ob0 = oracle.OracleBatch(g.params, E)
+        ob0.set_reset_pool(pool)
+        ob0.reset_from_pool()
+        assert (ob0.rollout_greedy(K // 2, auto_reset=True, policy=policy)[0] != first_acts).any()
+    finally:
+        oracle.OracleBatch.set_policy_epsilon(0.0)
+        env.close()
+
+
+def test_policy_epsilon_argument_checks(ccx):
+    from collectivecrossing_amd._lib import CcxError
+
+    env = ccx(Golden("g8_rollout_c1").config, 4)
+    for bad in (-0.1, 1.5, float("nan")):
+        with pytest.raises(CcxError, match="epsilon must be in"):
+            env.set_policy_epsilon(bad)
+    env.set_policy_epsilon(1.0)
+    env.set_policy_epsilon(0.0)
+    env.close()
 
 
 def test_consecutive_long_launches_with_the_adaptive_pace_equal_the_oracle(oracle, ccx):

@@ -128,3 +128,118 @@ def test_device_random_policy_stream_is_uniform_and_independent_of_splits(oracle
     np.testing.assert_array_equal(np.concatenate([o_lo, o_hi], axis=1).view(np.uint32), obs.view(np.uint32))
     (acts3, *_), _ = run(24, [120], seed=1235)
     assert (acts3 != acts).mean() > 0.5
+
+
+def _mix32(k):
+    k &= 0xFFFFFFFF
+    k ^= k >> 16
+    k = (k * 0x7FEB352D) & 0xFFFFFFFF
+    k ^= k >> 15
+    k = (k * 0x846CA68B) & 0xFFFFFFFF
+    k ^= k >> 16
+    return k
+
+
+def _eps_word(seed, g, j, t, a):
+    """include/ccx.h (ccx_set_policy_epsilon): the exploration word of agent a of global env g at step t of episode j."""
+    lo, hi = seed & 0xFFFFFFFF, (seed >> 32) ^ 0x5BD1E995
+    k = (g * 0x9E3779B1 + j * 0x85EBCA77 + t * 0xC2B2AE3D + a * 0x27D4EB2F + lo) & 0xFFFFFFFF
+    return _mix32(_mix32(k) ^ hi)
+
+
+@pytest.mark.parametrize("policy", ["greedy", "waiting"])
+def test_epsilon_greedy_draws_follow_the_documented_formula(oracle, policy):
+    """ccx_set_policy_epsilon restated in the oracle: an agent explores iff its counter-based word is below
+    epsilon * 2^32 (recomputed here in Python from the header's formula); otherwise it takes the epsilon-0
+    policy's action; an exploring action is the k-th valid one, k from the second draw (valid = wait, or a
+    target cell on the grid that no other active agent holds -- necessary conditions checked here); the
+    stream does not depend on how the rollout is cut into launches or the batch into shards."""
+    from _fixtures import Golden
+
+    from collectivecrossing_amd.reset import build_reset_pool
+    g = Golden("g4_c5_all_at_dest_greedy_25_25")
+    pool = build_reset_pool(g.config, 7, 33)
+    seed, eps, E, K, total = (77 << 32) | 12345, 0.3, 6, 60, 9
+    thr = int(eps * 2**32)
+    DX, DY = [1, 0, -1, 0, 0], [0, 1, 0, -1, 0]
+
+    def fresh(E_, off):
+        oracle.OracleBatch.set_rng_seed(seed)
+        oracle.OracleBatch.set_policy_epsilon(eps)
+        b = oracle.OracleBatch(g.params, E_, env_offset=off, total_envs=total)
+        b.set_reset_pool(pool)
+        b.reset_from_pool()
+        return b
+
+    try:
+        b = fresh(E, 0)
+        explored = asked = 0
+        all_acts = []
+        for s in range(K):
+            base = b.policy_actions(policy)                      # epsilon = 0 on the same pre-step state
+            x, y, active = b.x.copy(), b.y.copy(), b.active.copy()
+            t, j = b.step_count.copy(), b.episode.copy()
+            acts = b.rollout_greedy(1, auto_reset=True, policy=policy)[0][0]
+            all_acts.append(acts)
+            for e in range(E):
+                for a in range(g.N):
+                    if base[e, a] == 255:
+                        assert acts[e, a] == 255
+                        continue
+                    asked += 1
+                    u = _eps_word(seed, e, int(j[e]), int(t[e]), a)
+                    if u >= thr:
+                        assert acts[e, a] == base[e, a], (s, e, a)
+                        continue
+                    explored += 1
+                    act = int(acts[e, a])
+                    assert 0 <= act <= 4
+                    if act != 4:
+                        nx, ny = x[e, a] + DX[act], y[e, a] + DY[act]
+                        assert 0 <= nx <= g.config.width and 0 <= ny <= g.config.height   # (:515: inclusive)
+                        others = (np.arange(g.N) != a) & (active[e] != 0)
+                        assert not np.any(others & (x[e] == nx) & (y[e] == ny))
+        assert 0.25 * asked < explored < 0.35 * asked, (explored, asked)
+        assert b.counters.episodes > 0
+        whole = np.stack(all_acts)
+        b2 = fresh(E, 0)                                           # one launch instead of K
+        np.testing.assert_array_equal(b2.rollout_greedy(K, auto_reset=True, policy=policy)[0], whole)
+        lo, hi = fresh(4, 0), None                                 # two shards of the same global batch
+        a_lo = lo.rollout_greedy(K, auto_reset=True, policy=policy)[0]
+        hi = fresh(2, 4)
+        a_hi = hi.rollout_greedy(K, auto_reset=True, policy=policy)[0]
+        np.testing.assert_array_equal(np.concatenate([a_lo, a_hi], axis=1), whole)
+        oracle.OracleBatch.set_policy_epsilon(0.0)                 # epsilon 0 = the deterministic policy
+        b3 = fresh(E, 0)
+        oracle.OracleBatch.set_policy_epsilon(0.0)
+        d = b3.rollout_greedy(5, auto_reset=True, policy=policy)[0]
+        b4 = fresh(E, 0)
+        oracle.OracleBatch.set_policy_epsilon(0.0)
+        for s in range(5):
+            np.testing.assert_array_equal(b4.policy_actions(policy), d[s])
+            b4.rollout_greedy(1, auto_reset=True, policy=policy)
+    finally:
+        oracle.OracleBatch.set_policy_epsilon(0.0)
+
+
+def test_epsilon_one_picks_uniformly_among_the_valid_actions(oracle):
+    """epsilon = 1: every asked agent explores; a lone agent in the open (all five actions valid) draws each
+    action about one time in five."""
+    from _fixtures import Golden
+
+    from collectivecrossing_amd.reset import build_reset_pool
+    g = Golden("g7_n1_boarding_only")
+    pool = build_reset_pool(g.config, 3, 50)
+    try:
+        oracle.OracleBatch.set_rng_seed(99)
+        oracle.OracleBatch.set_policy_epsilon(1.0)
+        b = oracle.OracleBatch(g.params, 400)
+        b.set_reset_pool(pool)
+        b.reset_from_pool()
+        acts = b.rollout_greedy(30, auto_reset=True, policy="greedy")[0]
+        live = acts != 255
+        counts = np.bincount(acts[live], minlength=5)
+        assert counts.min() > 0.1 * live.sum(), counts     # border cells have fewer valid actions: loose bounds
+        assert counts[4] > 0.19 * live.sum(), counts        # wait is valid everywhere: at least its 1/5 share
+    finally:
+        oracle.OracleBatch.set_policy_epsilon(0.0)
