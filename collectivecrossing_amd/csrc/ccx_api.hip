@@ -330,6 +330,10 @@ int end_timed(ccx_handle* h) {
     return CCX_OK;
 }
 
+#ifdef CCX_LAG_TRACE
+int* g_lag_buf = nullptr;
+#endif
+
 int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* order, int auto_reset,
                 const ccx::KOut& out, int policy = 0, uint8_t* actions_out = nullptr) {
     if (out.obs && (reinterpret_cast<uintptr_t>(out.obs) & 15u))
@@ -357,6 +361,17 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     ccx::KParams kp = h->kp;
     // paired hand-offs for launches the kernel will not pace (same condition as in the kernel)
     kp.hand2 = (kp.pace_state && out.obs && K >= 16) ? 0u : (h->tun_hand2 != 0 ? 1u : 0u);
+#ifdef CCX_LAG_TRACE
+    {
+        static int* lag_buf = nullptr;
+        if (!lag_buf) CCX_HIP(hipMalloc(&lag_buf, 16 * 4096 * sizeof(int)));
+        CCX_HIP(hipMemsetAsync(lag_buf, 0x80, 16 * 4096 * sizeof(int), h->stream));
+        kp.lag_trace = lag_buf;
+        const int tiles_ = h->shape.num_blocks * h->shape.waves_per_block;
+        kp.lag_every = tiles_ >= 16 ? tiles_ / 16 : 1;
+        g_lag_buf = lag_buf;
+    }
+#endif
     const bool adaptive = kp.pace_state && kp.pace_adapt && out.obs && K >= 64;
     bool capturing = false;
     if (adaptive) {
@@ -940,4 +955,10 @@ int ccx_synchronize(ccx_handle* h) {
     return report_input_errors(h);
 }
 
+#ifdef CCX_LAG_TRACE
+int ccx_debug_lag_trace(int* host) {   // diagnostic build only (make variant DEFS=-DCCX_LAG_TRACE): [16][4096] ints of the last launch
+    if (!g_lag_buf) return -1;
+    return (int)hipMemcpy(host, g_lag_buf, 16 * 4096 * sizeof(int), hipMemcpyDeviceToHost);
+}
+#endif
 }  // extern "C"
