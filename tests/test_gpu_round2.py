@@ -280,7 +280,8 @@ def test_steady_state_launches_have_no_outliers(ccx):
     C2 launches (4096 envs x 8 agents, 500 env-steps each, full outputs) stay within a few per cent of their
     median -- a collapse of the drain rate costs 8-13 % of a launch (the chip's write limiter cuts in for ~0.5 ms,
     profiles/r02_lag_trace_*.txt) and must be a rare event, not a rhythm (round 1: one every 15-20 launches).
-    Bounds with room for the lease-to-lease spread: at most two launches above 1.05 x the median, none above 1.2 x."""
+    Bounds with room for the lease-to-lease spread: at most three launches above 1.05 x the median (the controller's own
+    spacing is one per 60-130 launches), none above 1.25 x."""
     import torch
 
     from bench import c2_config
@@ -303,7 +304,7 @@ def test_steady_state_launches_have_no_outliers(ccx):
     st = env.pace_state()
     env.close()
     assert st["paced"] == 1.0 and st["next_pace_ns"] > 0
-    assert over <= 2 and ms.max() < 1.20 * med, (over, ms.max() / med, sorted(ms)[-3:], st)
+    assert over <= 3 and ms.max() < 1.25 * med, (over, ms.max() / med, sorted(ms)[-3:], st)
 
 
 @pytest.mark.parametrize("E", [1024, 2048, 3072])
