@@ -114,7 +114,7 @@ int choose_shape(ccx_handle* h) {
         const size_t msz_ = (glog == 6) ? 8u : 4u;
         auto need = [&](int e) {
             const size_t units_ = (size_t)e * h->N * (3 + 2 * h->N);
-            return up(cells_ * 8u) + up(256u + 4096u + 7u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) +
+            return up(cells_ * 8u) + up(256u + ccx::kStageBytes + 7u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) +
                    up((units_ + 2u) * 2u);
         };
         if (need(1) <= 96u * 1024u)
@@ -135,7 +135,7 @@ int choose_shape(ccx_handle* h) {
             const size_t cells_ = (size_t)(h->params.width + 3) * (size_t)(h->params.height + 3);
             const size_t msz_ = (glog == 6) ? 8u : 4u;
             const size_t units_ = (size_t)max_ew * h->N * (3 + 2 * h->N);
-            if (up(cells_ * 8u) + up(256u + 4096u + 2u * 1056u + up((size_t)max_ew * 2u * (cells_ + 1u) * msz_)) +
+            if (up(cells_ * 8u) + up(256u + ccx::kStageBytes + 2u * 1056u + up((size_t)max_ew * 2u * (cells_ + 1u) * msz_)) +
                     up((units_ + 2u) * 2u) <= 96u * 1024u) {
                 small_batch = true;
                 ew = max_ew;
@@ -201,7 +201,7 @@ int choose_shape(ccx_handle* h) {
     const size_t occ_bytes = up16((size_t)ew * 2u * (cells + 1u) * msz);
     const size_t table = up16((size_t)(units + 2) * 2u);
     const size_t off_tiles = up16(cells * 8u);
-    const size_t off_ws = 256u + 4096u;                         // xch + stage ring (4 slots)
+    const size_t off_ws = 256u + ccx::kStageBytes;              // xch + stage ring
     const size_t off_occ = off_ws + (size_t)writers * 1056u;    // WSlot per writer
     size_t tile_stride = up16(off_occ + occ_bytes);
     size_t total = off_tiles + (size_t)tpb * tile_stride + table;

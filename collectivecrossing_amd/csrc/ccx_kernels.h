@@ -49,6 +49,9 @@ __host__ __device__ inline uint32_t explore_action(uint32_t u, uint32_t free_dir
     return (uint32_t)__builtin_ctz(vm);
 #endif
 }
+// hand-off ring between the sim wave and the writer waves of a tile: slots of 64 x 16 bytes; a hand-off of two env-steps
+// at once (KParams::hand2) needs four slots
+constexpr uint32_t kStageSlots = 4, kStageBytes = kStageSlots * 1024u;
 enum : uint32_t { CCX_K_EF_ALL_TERM = 1u, CCX_K_EF_ALL_TRUNC = 2u, CCX_K_EF_RESET = 4u };
 
 // kernel parameters (passed by value; lives in SGPRs / the kernarg segment)

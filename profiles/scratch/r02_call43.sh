@@ -1,0 +1,14 @@
+#!/bin/bash
+# hand-offs of four env-steps (ring of 8 slots) vs two, unpaced launches
+set -e
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+export CCX_PACE_MEMORY=0
+R=collectivecrossing_amd/csrc/_diag/libccx_ring8.so
+timeout -k 10 200 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "arbitrary or rollout_equals or autoreset" -p no:cacheprovider 2>&1 | grep -v amdgpu.ids | tail -2
+for rep in 1 2 3; do
+  for E in 4096 2048 1024; do
+    timeout -k 10 100 python3 profiles/scratch/sim_only.py $E 2>&1 | grep -v amdgpu.ids | tail -1
+    CCX_DIAG_LIB=$R timeout -k 10 100 python3 profiles/scratch/sim_only.py $E hand2=1 2>&1 | grep -v amdgpu.ids | tail -1
+    CCX_DIAG_LIB=$R timeout -k 10 100 python3 profiles/scratch/sim_only.py $E hand2=2 2>&1 | grep -v amdgpu.ids | tail -1
+  done
+done
