@@ -45,6 +45,14 @@ traj, chosen = batch.rollout_greedy(K, auto_reset=True, out=traj)
 print("greedy rollout: mean live reward", float(traj.reward[traj.agent_flags & 4 != 0].mean()),
       "episodes so far", batch.counters()["episodes"])
 
+# 3b. the reference's default scripted baseline is epsilon-greedy (create_greedy_policy(epsilon=0.1)): same launch, the
+#     exploration draws come from a counter-based RNG on the device (the host classes keep numpy's stream)
+batch.set_rng_seed(42)
+batch.set_policy_epsilon(0.1)
+traj, chosen = batch.rollout_greedy(K, auto_reset=True, out=traj)
+print("epsilon-greedy rollout: mean live reward", float(traj.reward[traj.agent_flags & 4 != 0].mean()))
+batch.set_policy_epsilon(0.0)
+
 # 4. consumers on the GPU: (x, y, type, active) once per agent instead of the N-fold rows; expand what you sample
 del traj
 small = batch.rollout(actions, auto_reset=True, want_obs=False, want_compact=True)
