@@ -371,3 +371,46 @@ def test_device_random_rollout_equals_the_oracle(oracle, ccx, cfg_name, E, K):
     np.testing.assert_array_equal(np.concatenate([_np(res.env_flags), _np(res2.env_flags)]), o_ef)
     assert env.counters() == ob.counters.as_dict() and ob.counters.moves > 0
     env.close()
+
+
+@pytest.mark.parametrize("name,eps", [("g4_c5_all_at_dest_greedy_25_25", 0.0), ("g4_c5_all_at_dest_greedy_32_32", 0.0),
+                                      ("g4_c5_all_at_dest_greedy_25_25", 0.1)])
+def test_full_size_c5_greedy_rollout_equals_the_oracle(oracle, ccx, name, eps):
+    """BASELINE configs[4] at its full size -- 1024 envs x 64 (and the reference-legal 50) agents on the 32x16 grid,
+    the greedy policy evaluated inside the kernel, AllAtDestination, auto-reset: the exact launch the C5 bench
+    figures come from (one env per wave, three writer waves, 1024 workgroups in one round, tiles phased, grouped tile
+    map; N = 50: tile regions that begin and end mid-line, i.e. the edge-iteration instantiation), 20 paced steps,
+    every output bit-equal to the oracle.  Also with the exploration draws of ccx_set_policy_epsilon."""
+    from collectivecrossing_amd.reset import build_reset_pool
+
+    g = Golden(name)
+    E, K = 1024, 20
+    pool = build_reset_pool(g.config, 500, 300)
+    ob, env = oracle.OracleBatch(g.params, E), ccx(g.config, E)
+    try:
+        for b in (ob, env):
+            b.set_reset_pool(pool)
+            b.reset_from_pool()
+        oracle.OracleBatch.set_rng_seed(9)
+        oracle.OracleBatch.set_policy_epsilon(eps)
+        env.set_rng_seed(9)
+        env.set_policy_epsilon(eps)
+        for launch in range(2):           # the second launch starts mid-episode, from the state the first one left
+            o_act, o_obs, o_rew, o_af, o_ef = ob.rollout_greedy(K, auto_reset=True)
+            res, acts = env.rollout_greedy(K, auto_reset=True)
+            np.testing.assert_array_equal(_np(acts), o_act)
+            np.testing.assert_array_equal(_np(res.agent_flags), o_af)
+            np.testing.assert_array_equal(_np(res.env_flags), o_ef)
+            np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64))
+            got = _np(res.obs).view(np.uint32)
+            del res
+            np.testing.assert_array_equal(got, o_obs.view(np.uint32))
+            del got, o_obs
+        shape = env.launch_shape()
+        assert (shape["writers_per_tile"], shape["waves_per_block"], shape["num_blocks"]) == (3, 1, 1024)
+        assert shape["num_blocks"] == shape["resident_blocks"]
+        assert env.step_pace_ns() > 0                           # a paced launch
+        assert env.counters() == ob.counters.as_dict()
+    finally:
+        oracle.OracleBatch.set_policy_epsilon(0.0)
+        env.close()
