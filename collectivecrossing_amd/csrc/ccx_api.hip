@@ -347,6 +347,12 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
         CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state), 0, 8, h->stream));   // floor, cliff memory = 0
         CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state + h->pace_slot),
                                   (int)h->pace_init_fp, 1, h->stream));
+        // A start value from the caller (ccx_set_step_pace_start: the pace a previous handle of this shape settled at)
+        // is also the first FLOOR: without one the controller descends 1.6 % per launch until its first collapse,
+        // which a process that already knows its pace can skip -- and the first milliseconds of a process collapse
+        // at paces that are fine later.  The floor decays as always (0.1 % per launch at first, then faster).
+        if (h->pace_start_ns > 0.0f && h->step_pace_ns == 0)
+            CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state + 2), (int)h->pace_init_fp, 1, h->stream));
         h->pace_dirty = false;
     }
     h->kp.pace_slot = h->pace_slot;

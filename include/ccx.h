@@ -359,7 +359,9 @@ int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step);
 int ccx_get_pace_state(ccx_handle* h, float* out6);
 /* Where the ADAPTIVE controller starts (ns per env-step; 0 = the library's assumption of 6.8 TB/s): a
  * caller that remembers the pace a previous handle of the same shape converged to (ccx_get_step_pace)
- * skips the descent of the first launches.  Restarts the controller. */
+ * skips the descent of the first launches; the value is also the controller's first floor (it decays like any
+ * floor), so that the start of a process is not spent probing below a pace that is already known.  Restarts the
+ * controller. */
 int ccx_set_step_pace_start(ccx_handle* h, float ns_per_env_step);
 /* Performance experiments without an ABI change; results never depend on a tunable.  -1 = the library's
  * choice for the launch shape (pace_phase, tile_map).
