@@ -65,3 +65,27 @@ def test_rccl_is_never_silently_replaced():
             "from collectivecrossing_amd import sharding; sharding.init_from_env(backend='nccl')" % str(ROOT))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "needs a GPU" in p.stderr
+
+
+@pytest.mark.timeout(300)
+def test_the_drivers_own_launcher_reaches_the_same_code():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` (how the driver starts
+    N > 1): bench.py finds RANK / WORLD_SIZE in the environment, does not spawn anything itself, and rank 0 alone
+    prints the line."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ, CCX_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
+                        "--gpus", "2", "--rehearse"], capture_output=True, text=True, timeout=280, env=e, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["launcher"] == "torch.distributed.run" and d["n_gpus"] == 2 and d["per_rank"] == [0.0, 1.0]
+    assert list(d["counters"].values()) == [3 * (q + 1) for q in range(6)]
