@@ -280,9 +280,11 @@ int choose_shape(ccx_handle* h) {
     // C3, C5) drain 5-10 % faster when the tiles of a round are phased over the step
     // period in tile order and groups of 16 adjacent tiles go to one XCD, dealt round-robin: the chip then
     // writes one window that sweeps through the slab instead of 1000+ regions at once (C3 0.80 -> 0.86,
-    // C5-64 0.79 -> 0.89, C5-50 0.77 -> 0.83 of the HBM peak in one call).  Small single-writer tiles (C2)
-    // show no difference and keep the common phase and the XCD-contiguous mapping.
-    const bool big_tiles = !small_tiles;
+    // C5-64 0.79 -> 0.89, C5-50 0.77 -> 0.83 of the HBM peak in one call).  Small tiles (C2: 10 KB per tile
+    // and step) show no difference while there are two of them per CU (4096 envs) and keep the common phase and
+    // the XCD-contiguous mapping; LARGER batches of small tiles are 1000+ regions at once again and gain the same
+    // way (C2 geometry, one call: 16 384 envs 0.879 -> 0.908, 32 768 envs in two rounds 0.830 -> 0.882).
+    const bool big_tiles = !small_tiles || (long long)tiles >= 4ll * h->num_cus;
     k.pace_phase = (uint32_t)(h->tun_pace_phase >= 0 ? h->tun_pace_phase : (big_tiles ? 1 : 0));
     // groups of ~1 MiB of one step's slab per XCD: g workgroups with g * (bytes a workgroup writes per step)
     // closest to 1 MiB, a power of two in 1..32 (C5-64: 16 x 67 KB, C3: 8 x 137 KB)

@@ -18,7 +18,8 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 fixed = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # ns per env-step, -1 = pacing off, 0 = adaptive
 cfg, E = workload_config(wl)
-K = 500 if wl == "c2" else 250
+E = int(os.environ.get("CCX_SWEEP_E", E))                     # a larger / smaller batch of the same geometry
+K = int(os.environ.get("CCX_TRACE_K", 500 if wl == "c2" else 250))
 env = BatchedCollectiveCrossing(cfg, E)
 env.set_timing(True)
 if fixed:

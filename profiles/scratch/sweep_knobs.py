@@ -27,6 +27,7 @@ combos = json.loads(sys.argv[5]) if len(sys.argv) > 5 else [
 
 for w in workloads:
     cfg, E = workload_config(w)
+    E = int(os.environ.get("CCX_SWEEP_E", E))          # a larger / smaller batch of the same geometry
     policy = "greedy" if w.startswith("c5") else "random"
     traj = None
     for rep in range(2):
