@@ -500,6 +500,9 @@ def run_rank(args) -> int:
                        "policy": args.policy if not args.epsilon else f"{args.policy}, epsilon {args.epsilon} (device draws)",
                        "envs_per_gpu": E, "global_envs": total, "agents": N, "obs_len": L,
                        "step": "one fused rollout launch over an action batch [env_steps_per_step, envs, agents]",
+                       "trajectory_buffer": ("every launch rewrites ONE set of [steps, envs, agents] output buffers (a fixed RL rollout "
+                                             "buffer, %.2f GB here); launches that cycle through > 3 GB of output memory sustain "
+                                             "0.86-0.88 of the peak instead of 0.90 (DESIGN.md 3.6)") % (chunk * E * N * rollout_bytes_per_agent_step(N) / 1e9),
                        "env_steps_per_step": chunk, "steps_per_launch": chunk,
                        "ms_per_env_step": elapsed * 1e3 / (args.steps * chunk),
                        "settle_launches": settle,
