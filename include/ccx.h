@@ -372,7 +372,7 @@ int ccx_set_step_pace_start(ccx_handle* h, float ns_per_env_step);
  *                  per XCD dealt round-robin (1 = tile = workgroup index)
  *   "writer_roles" 1 = writer wave 0 of a tile writes the small outputs only and the others share the observation
  *                  rows, 0 = every writer takes a share of the rows (writer 0 the small outputs on top), -1 = by
- *                  batch size (split for batches too small to be memory-bound)
+ *                  launch shape (split wherever a tile of at most 12 store iterations per step has two or more writers)
  *   "hand2"        1 (default) = launches that are not paced hand two env-steps at a time from the simulating
  *                  wavefront to the writer wavefronts (one barrier per two steps), 0 = one per step */
 int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value);
