@@ -225,15 +225,20 @@ class BatchedCollectiveCrossing:
 
     # ------------------------------------------------------------------ scripted policy
     def policy_actions(self, policy: str = "greedy", out: torch.Tensor | None = None) -> torch.Tensor:
-        """Epsilon-0 ``GreedyPolicy`` / ``WaitingPolicy`` action of every live agent for the current
-        state, u8 [E, N] (255 for agents that are terminated or truncated) -- ``ccx_policy_actions``."""
+        """``GreedyPolicy`` / ``WaitingPolicy`` action of every live agent for the current state, u8 [E, N]
+        (255 for agents that are terminated or truncated) -- ``ccx_policy_actions``; epsilon 0 unless
+        :meth:`set_policy_epsilon` is in effect (then the same draws as inside ``rollout_policy``)."""
         if out is None:
             out = self._new((self.num_envs, self.num_agents), torch.uint8)
         check(self._lib.ccx_policy_actions(self._h, _abi.POLICIES[policy], _ptr(out)))
         return out
 
     def greedy_actions(self, out: torch.Tensor | None = None) -> torch.Tensor:
-        return self.policy_actions("greedy", out)
+        """``GreedyPolicy(epsilon=0)`` for every live agent (``ccx_greedy_actions``; never explores)."""
+        if out is None:
+            out = self._new((self.num_envs, self.num_agents), torch.uint8)
+        check(self._lib.ccx_greedy_actions(self._h, _ptr(out)))
+        return out
 
     # ------------------------------------------------------------------ compute
     def observe(self, out: torch.Tensor | None = None) -> torch.Tensor:

@@ -656,7 +656,9 @@ int ccx_policy_actions(ccx_handle* h, int32_t policy, uint8_t* actions) {
 int ccx_greedy_actions(ccx_handle* h, uint8_t* actions) {
     if (!h || !actions) return fail(CCX_EINVAL, "NULL argument");
     CCX_HIP(hipSetDevice(h->device));
-    hipError_t e = ccx::launch_greedy_actions(h->stream, h->kp, h->st, h->cell_info, actions, CCX_POLICY_GREEDY);
+    ccx::KParams kp = h->kp;
+    kp.eps_thr = 0u;                               // (always the deterministic policy; ccx_policy_actions has the epsilon)
+    hipError_t e = ccx::launch_greedy_actions(h->stream, kp, h->st, h->cell_info, actions, CCX_POLICY_GREEDY);
     if (e != hipSuccess) return fail(CCX_EHIP, "greedy kernel launch failed: %s", hipGetErrorString(e));
     return CCX_OK;
 }

@@ -1,4 +1,4 @@
-// ccx_policy.hip -- the reference's GreedyPolicy with epsilon = 0
+// ccx_policy.hip -- the reference's GreedyPolicy (epsilon = 0, or epsilon-greedy with the device's counter-based draws)
 // (src/baseline_policies/greedy_policy.py:33-449) for every agent of every env, one thread per
 // (env, agent).  The rule reads only the PRE-step state (the reference computes all actions before
 // env.step, scripts/run_greedy_policy_demo.py:67-109), so agents are independent:
@@ -38,31 +38,36 @@ __global__ void greedy_actions_kernel(const KParams p, const KState st,
     const uint32_t nv = cw & 0xFu;   // enterable neighbours
     uint32_t cand = greedy_candidates(p, i < p.Nb, cx, cy);
     const size_t base = (size_t)env * p.N;
+    bool waits = false;
     if (policy == CCX_K_POLICY_WAITING && i < p.Nb && !(cw & 0x10u)) {   // waiting_policy.py:92-100
-        bool pending = false;
         for (int b = p.Nb; b < p.N; ++b)                                  // :119-129
-            pending |= !(st.terminated[base + b] || st.truncated[base + b]) && st.y[base + b] != p.edy;
-        if (pending) {
-            actions[t] = 4;
-            return;
-        }
+            waits |= !(st.terminated[base + b] || st.truncated[base + b]) && st.y[base + b] != p.edy;
     }
-    uint32_t chosen = 4u;
-    for (int k = 0; k < 6; ++k) {   // candidate 0 = primary, 1..4 preference list, 5 = wait
-        const uint32_t a = k < 5 ? ((cand >> (4 * k)) & 0xFu) : 4u;
-        if (a == 4u) {
-            chosen = 4u;
-            break;
-        }
+    // directions this agent could move in: the neighbour bit of its cell and no other ACTIVE agent on the target
+    // (env._is_move_valid, collectivecrossing.py:345-369) -- what both the policy's fallback list and an
+    // epsilon draw choose from
+    uint32_t free_dirs = 0u;
+    for (uint32_t a = 0; a < 4u; ++a) {
         if (!((nv >> a) & 1u)) continue;
         const int nx = cx + (a == 0u) - (a == 2u), ny = cy + (a == 1u) - (a == 3u);
         bool taken = false;
         for (int b = 0; b < p.N; ++b)
             taken |= (b != i) && st.active[base + b] && st.x[base + b] == nx && st.y[base + b] == ny;
-        if (!taken) {
+        if (!taken) free_dirs |= 1u << a;
+    }
+    uint32_t chosen = 4u;
+    for (int k = 0; k < 6 && !waits; ++k) {   // candidate 0 = primary, 1..4 preference list, 5 = wait
+        const uint32_t a = k < 5 ? ((cand >> (4 * k)) & 0xFu) : 4u;
+        if (a == 4u) break;
+        if ((free_dirs >> a) & 1u) {
             chosen = a;
             break;
         }
+    }
+    if (p.eps_thr) {   // epsilon-greedy with the device's counter-based draws (include/ccx.h: ccx_set_policy_epsilon)
+        const uint32_t u = random_word(p.rng_lo, p.rng_hi ^ kEpsStream, (uint32_t)(p.env_offset + env), (uint32_t)st.episode[env],
+                                       (uint32_t)st.step_count[env], (uint32_t)i);
+        if (u < p.eps_thr) chosen = explore_action(u, free_dirs);
     }
     actions[t] = (uint8_t)chosen;
 }

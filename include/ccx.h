@@ -278,7 +278,8 @@ int ccx_set_rng_seed(ccx_handle* h, uint64_t seed);
  *     action   =  the ((mix(u + 0x9E3779B9) * count) >> 32)-th valid action in ascending order, count = #valid
  * pinned by the oracle's restatement (ccxo_set_policy_epsilon).  0 (the default) = the deterministic policies.
  * The host classes of collectivecrossing_amd/baseline_policies.py keep the reference's own RandomState stream.
- * ccx_policy_actions / ccx_greedy_actions are always epsilon = 0.
+ * ccx_policy_actions honours it as well (same draws: a loop of ccx_policy_actions + ccx_step takes the actions
+ * ccx_rollout_policy takes); ccx_greedy_actions is always epsilon = 0.
  */
 int ccx_set_policy_epsilon(ccx_handle* h, double epsilon);
 

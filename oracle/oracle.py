@@ -76,6 +76,8 @@ def lib() -> C.CDLL:
         L.ccxo_rollout_policy.restype = None
         L.ccxo_policy_actions.argtypes = [PP, C.c_int32, C.c_int32] + [V] * 6
         L.ccxo_policy_actions.restype = None
+        L.ccxo_policy_actions_eps.argtypes = [PP, C.c_int32, C.c_int32, C.c_int64] + [V] * 8
+        L.ccxo_policy_actions_eps.restype = None
         L.ccxo_set_rng_seed.argtypes = [C.c_uint64]
         L.ccxo_set_rng_seed.restype = None
         L.ccxo_set_policy_epsilon.argtypes = [C.c_double]
@@ -188,9 +190,17 @@ class OracleBatch:
         """randomness_factor of the greedy / waiting policies in rollout_greedy (process-wide in the oracle)."""
         lib().ccxo_set_policy_epsilon(C.c_double(float(epsilon)))
 
-    def policy_actions(self, policy: str = "greedy") -> np.ndarray:
-        """Epsilon-0 GreedyPolicy / WaitingPolicy action of every live agent, u8 [E, N]."""
+    def policy_actions(self, policy: str = "greedy", with_epsilon: bool = False) -> np.ndarray:
+        """GreedyPolicy / WaitingPolicy action of every live agent, u8 [E, N]: epsilon 0, or (with_epsilon) with
+        the exploration draws of set_policy_epsilon, as ccx_policy_actions does."""
         out = np.empty((self.E, self.N), np.uint8)
+        if with_epsilon:
+            lib().ccxo_policy_actions_eps(C.byref(self.params), self.POLICIES[policy], self.E, int(self.env_offset),
+                                          _p(self.x, np.int32), _p(self.y, np.int32),
+                                          _p(self.active, np.uint8), _p(self.terminated, np.uint8),
+                                          _p(self.truncated, np.uint8), _p(self.step_count, np.int32),
+                                          _p(self.episode, np.int32), _p(out, np.uint8))
+            return out
         lib().ccxo_policy_actions(C.byref(self.params), self.POLICIES[policy], self.E,
                                   _p(self.x, np.int32), _p(self.y, np.int32),
                                   _p(self.active, np.uint8), _p(self.terminated, np.uint8),

@@ -865,3 +865,42 @@ def test_errors_are_loud(ccx):
     with pytest.raises(ValueError):
         env.step(np.zeros((4, 2), np.uint8))
     env.close()
+
+
+@pytest.mark.parametrize("policy,eps", [("greedy", 0.3), ("waiting", 0.5), ("greedy", 1.0)])
+def test_stepwise_policy_loop_takes_the_actions_of_the_fused_rollout(oracle, ccx, policy, eps):
+    """ccx_policy_actions honours ccx_set_policy_epsilon with the draws of the fused rollout: K rounds of
+    policy_actions + step take exactly the actions (and produce the outputs) of one rollout_policy(K) from the same
+    start, and equal the oracle's stand-alone restatement state by state; greedy_actions stays epsilon 0."""
+    from collectivecrossing_amd.reset import build_reset_pool
+
+    g = Golden("g4_c5_all_at_dest_greedy_25_25")
+    E, K = 40, 45
+    pool = build_reset_pool(g.config, 21, 90)
+    fused, loop, ob = ccx(g.config, E), ccx(g.config, E), oracle.OracleBatch(g.params, E)
+    try:
+        for b in (fused, loop, ob):
+            b.set_reset_pool(pool)
+            b.reset_from_pool()
+        oracle.OracleBatch.set_rng_seed(31)
+        oracle.OracleBatch.set_policy_epsilon(eps)
+        for b in (fused, loop):
+            b.set_rng_seed(31)
+            b.set_policy_epsilon(eps)
+        res, acts = fused.rollout_policy(K, policy, auto_reset=False)
+        differs = 0
+        for s in range(K):
+            a = loop.policy_actions(policy)
+            np.testing.assert_array_equal(_np(a), ob.policy_actions(policy, with_epsilon=True), err_msg=f"step {s}")
+            np.testing.assert_array_equal(_np(a), _np(acts[s]), err_msg=f"step {s}")
+            differs += int((_np(loop.greedy_actions()) != _np(a)).sum()) if policy == "greedy" else 0
+            out = loop.step(a)
+            ob.step(_np(a))
+            np.testing.assert_array_equal(_np(out.obs).view(np.uint32), _np(res.obs[s]).view(np.uint32), err_msg=f"step {s}")
+            np.testing.assert_array_equal(_np(out.agent_flags), _np(res.agent_flags[s]))
+        assert policy != "greedy" or differs > 0          # the draws did replace greedy choices
+        assert loop.counters() == fused.counters() == ob.counters.as_dict()
+    finally:
+        oracle.OracleBatch.set_policy_epsilon(0.0)
+        fused.close()
+        loop.close()
