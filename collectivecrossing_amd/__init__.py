@@ -1,7 +1,8 @@
 """collectivecrossing_amd -- MI355X-native batched CollectiveCrossing step.
 
 ``CollectiveCrossingEnv`` (dict API, drop-in for the reference), ``BatchedCollectiveCrossing``
-(array API) and ``VectorCollectiveCrossing`` (many envs behind per-env dict views) all run the step on
+(array API), ``VectorCollectiveCrossing`` (many envs behind per-env dict views) and
+``rllib.BatchedMultiAgentEnv`` (the batch as one RLlib ``MultiAgentEnv`` with flat agent ids) all run the step on
 the GPU through libccx (``include/ccx.h``); there is no CPU implementation of the step path in this
 package.
 """
@@ -9,7 +10,8 @@ package.
 from .configs import CollectiveCrossingConfig  # noqa: F401
 
 __version__ = "0.3.0"
-__all__ = ["CollectiveCrossingConfig", "CollectiveCrossingEnv", "BatchedCollectiveCrossing", "VectorCollectiveCrossing"]
+__all__ = ["CollectiveCrossingConfig", "CollectiveCrossingEnv", "BatchedCollectiveCrossing", "VectorCollectiveCrossing",
+           "BatchedMultiAgentEnv"]
 
 
 def __getattr__(name):  # lazy: importing the configs must not pull in torch
@@ -22,6 +24,9 @@ def __getattr__(name):  # lazy: importing the configs must not pull in torch
     if name == "VectorCollectiveCrossing":
         from .vector import VectorCollectiveCrossing
         return VectorCollectiveCrossing
+    if name == "BatchedMultiAgentEnv":
+        from .rllib import BatchedMultiAgentEnv
+        return BatchedMultiAgentEnv
     raise AttributeError(name)
 
 

@@ -66,6 +66,20 @@ class EnvView:
     def observations(self) -> dict[str, np.ndarray]:
         return self._vec.view(self.index)[0]
 
+    # A view is not a steppable env: the E envs of the batch advance TOGETHER in one kernel launch.
+    def _batch_only(self, what: str):
+        raise RuntimeError(
+            f"EnvView.{what}() is not available: env {self.index} is one of {self._vec.num_envs} envs of a batch that is "
+            "stepped as a whole on the GPU.  Use VectorCollectiveCrossing.step / step_dicts / reset (all envs at once), "
+            "collectivecrossing_amd.rllib.BatchedMultiAgentEnv (one RLlib MultiAgentEnv over the batch, flat agent ids), "
+            "or collectivecrossing_amd.CollectiveCrossingEnv for a single env with the reference's reset()/step().")
+
+    def reset(self, *, seed=None, options=None):
+        self._batch_only("reset")
+
+    def step(self, action_dict):
+        self._batch_only("step")
+
 
 class VectorCollectiveCrossing:
     """E independent envs; array API in, array API out, dict views on demand."""
@@ -117,6 +131,9 @@ class VectorCollectiveCrossing:
         self._episodes = np.zeros(E, np.int64)
         self._final: dict[int, tuple] = {}
         self._reset_rows = None
+        # envs restarted by step_dicts(auto_reset=True) after the last step: their rows in `last.obs` are the NEW
+        # episode's first observations and every agent's row counts as handed out (policy_inputs' mask)
+        self._restarted = torch.zeros((E,), dtype=torch.bool, device=dev)
 
     # ------------------------------------------------------------------ batch API (device)
     def reset(self, seeds, env_mask=None) -> torch.Tensor:
@@ -129,6 +146,7 @@ class VectorCollectiveCrossing:
             self._done[m.to(self._done.device).bool()] = False
         self.last, self._host_valid, self._done_host = None, False, None
         self._reset_rows = None
+        self._restarted.zero_()
         return obs
 
     def step(self, actions, order=None) -> StepResult:
@@ -146,6 +164,7 @@ class VectorCollectiveCrossing:
         self.last = out
         with torch.cuda.stream(b._stream):
             self._done |= (out.agent_flags & (_abi.AF_TERMINATED | _abi.AF_TRUNCATED)) != 0
+            self._restarted.zero_()
         self._host_valid, self._done_host = False, None
         self._final = {}
         return out
@@ -182,7 +201,7 @@ class VectorCollectiveCrossing:
             if self.last is None:
                 raise RuntimeError("no step yet")
             obs = self.last.obs
-            emitted = (self.last.agent_flags & _abi.AF_OBS) != 0
+            emitted = ((self.last.agent_flags & _abi.AF_OBS) != 0) | self._restarted[:, None]
         else:
             emitted = torch.ones(obs.shape[:2], dtype=torch.bool, device=obs.device)
         nb = self.num_boarding
@@ -216,7 +235,13 @@ class VectorCollectiveCrossing:
                 seeds = (seed0 + self._episodes * E + np.arange(E)).astype(np.uint64)
                 obs = self.batch.reset(seeds, env_mask=done.astype(np.uint8))
                 with torch.cuda.stream(self.batch._stream):
-                    self._done[torch.from_numpy(done).to(self._done.device)] = False
+                    m = torch.from_numpy(done).to(self._done.device)
+                    self._done[m] = False
+                    # the device path sees the new episode too: the restarted envs' rows of `last.obs` (what
+                    # policy_inputs() / obs_dlpack() hand out) become the reset observations, like view(e) on the host;
+                    # the terminal rows stay available under infos["__final__"] only
+                    self._out.obs.copy_(torch.where(m[:, None, None], obs, self._out.obs))
+                    self._restarted.copy_(m)
                 self._done_host = None
                 self._reset_rows = (done, obs.cpu().numpy())
             else:

@@ -121,6 +121,16 @@ def test_step_dicts_auto_reset_restarts_finished_envs_with_the_reference_placeme
                 want, _ = probe.reset(seed=1000 + episode * E + e)     # the reference-exact placement (host twin)
                 assert all(np.array_equal(o[a], want[a]) for a in want)
                 assert vec.envs[e].agents == vec.agent_ids
+                # the DEVICE path shows the new episode as well: last.obs / policy_inputs() hold the reset
+                # observations of a restarted env, every row counts as handed out; the terminal rows live in __final__
+                dev_rows = vec.last.obs[e].cpu().numpy()
+                assert all(np.array_equal(dev_rows[i], o[a]) for i, a in enumerate(vec.agent_ids))
+                pin = vec.policy_inputs()
+                assert bool(pin["boarding"]["mask"][e].all()) and bool(pin["exiting"]["mask"][e].all())
+                assert any(not np.array_equal(fo[a], o[a]) for a in fo)
+            else:
+                dev_rows = vec.last.obs[e].cpu().numpy()
+                assert all(np.array_equal(dev_rows[vec.agent_ids.index(a)], o[a]) for a in o)
     assert restarts == 3 * E
     probe.close()
     vec.close()
