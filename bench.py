@@ -221,30 +221,51 @@ def spawn_ranks(n: int, argv: list[str]) -> int:
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
     relay = threading.Thread(target=lambda: [print(ln, end="", flush=True) for ln in procs[0].stdout], daemon=True)
     relay.start()
-    deadline = time.time() + float(os.environ.get("CCX_BENCH_LAUNCH_TIMEOUT", "1500"))
+    # below the harness limits (gpurun 1200 s, pytest 600 s): the launcher's own clean-up must be able to fire
+    deadline = time.time() + float(os.environ.get("CCX_BENCH_LAUNCH_TIMEOUT", "1100"))
     worst = 0
     alive = set(range(n))
-    while alive:
-        for r in sorted(alive):
-            rc = procs[r].poll()
-            if rc is not None:
-                alive.discard(r)
-                if rc != 0:
-                    worst = worst or rc
-        if (worst or time.time() > deadline) and alive:
-            # one rank failed (or the job hangs at a rendezvous): end exactly the processes started here
-            why = f"rank exit code {worst}" if worst else "launcher timeout"
-            print(f"[bench] {why}: stopping ranks {sorted(alive)}", file=sys.stderr)
-            for r in alive:
-                procs[r].terminate()
-            for r in alive:
-                try:
-                    procs[r].wait(timeout=20)
-                except subprocess.TimeoutExpired:
-                    procs[r].kill()
-            worst = worst or 124
-            break
-        time.sleep(0.05)
+
+    def stop_ranks(why: str) -> None:
+        """End exactly the processes started here: terminate, then kill what ignores it."""
+        live = [r for r in sorted(alive) if procs[r].poll() is None]
+        if not live:
+            return
+        print(f"[bench] {why}: stopping ranks {live}", file=sys.stderr)
+        for r in live:
+            procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+
+    def on_signal(signum, _frame):            # SIGTERM / SIGINT to the launcher must not orphan ranks holding GPUs
+        raise KeyboardInterrupt(f"signal {signum}")
+
+    import signal
+    old_handlers = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        while alive:
+            for r in sorted(alive):
+                rc = procs[r].poll()
+                if rc is not None:
+                    alive.discard(r)
+                    if rc != 0:
+                        worst = worst or rc
+            if (worst or time.time() > deadline) and alive:
+                # one rank failed (or the job hangs at a rendezvous)
+                stop_ranks(f"rank exit code {worst}" if worst else "launcher timeout")
+                worst = worst or 124
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt as stop:
+        stop_ranks(f"launcher interrupted ({stop})")
+        worst = worst or 130
+    finally:
+        stop_ranks("launcher exiting")        # (no-op unless something above raised)
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
     relay.join(timeout=5)
     return worst
 

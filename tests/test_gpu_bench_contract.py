@@ -78,15 +78,51 @@ def test_bare_command_with_two_ranks_sharing_the_gpu():
     assert d["value"] <= sum(d["per_rank_env_steps_per_sec"]) * 1.0001
 
 
+@pytest.mark.timeout(1000)
+@pytest.mark.parametrize("direct", [False, True], ids=["torch_distributed", "direct_rccl"])
+def test_two_rccl_ranks_when_the_box_has_two_gpus(direct):
+    """Self-activating evidence of the N > 1 path: on a box with >= 2 GPUs the BARE command
+    `bench.py --gpus 2` spawns two ranks that form a real RCCL group -- through torch.distributed and through the
+    C-ABI's own ncclAllReduce (`ccx_rccl_allreduce_counters`) -- the 48-byte counter reduction sums both shards and
+    the two ranks run at the same rate.  One-GPU boxes skip (the refusal test below covers them).  The reference's
+    only parallelism is one env per EnvRunner process (examples/training_script.py:84); one shard per GPU is the
+    equivalent."""
+    import torch
+    if torch.cuda.device_count() < 2:            # (counting devices does not initialise the GPU)
+        pytest.skip("needs >= 2 GPUs: RCCL refuses two ranks on one device")
+    e = {k: v for k, v in os.environ.items()
+         if k not in ("CCX_DIST_BACKEND", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", *(["--direct-rccl"] if direct else [])],
+                       capture_output=True, text=True, timeout=900, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["collective_backend"] == "nccl" and d["launcher"] == "bench.py"
+    assert c["global_envs"] == 2 * c["envs_per_gpu"]
+    assert d["counters"]["env_steps"] == 3 * c["env_steps_per_step"] * c["global_envs"]      # summed over both ranks
+    assert d["counters"]["agent_steps"] == d["counters"]["env_steps"] * c["agents"]
+    if direct:
+        assert d["counters_allreduce"] == "ccx_rccl_allreduce_counters (2 RCCL rank(s))"
+    else:
+        assert d["counters_allreduce"] == "torch.distributed"
+    rates = d["per_rank_env_steps_per_sec"]
+    assert len(rates) == 2 and min(rates) > 0.85 * max(rates), rates                          # weak scaling: same work, same rate
+    assert d["value"] <= sum(rates) * 1.0001 and d["value"] > 1.5 * min(rates) * 0.85
+    assert d["cpu_baseline"] is None and "secondary" not in d
+
+
 def test_rccl_group_of_one_rank_per_gpu_only():
     """With backend nccl (the default on a GPU box) two ranks on one GPU are refused loudly -- never
     downgraded to another backend."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box can really run two RCCL ranks (test_two_rccl_ranks_when_the_box_has_two_gpus)")
     e = dict(os.environ)
     e.pop("CCX_DIST_BACKEND", None)
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=e)
-    import torch
-    if torch.cuda.device_count() >= 2:
-        pytest.skip("this box can really run two RCCL ranks")
     assert p.returncode != 0 and "one GPU per" in p.stderr
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
