@@ -77,7 +77,7 @@ std::vector<unsigned long long> build_cell_table(const ccx_params& p) {
                 sd_b = -(y > p.boarding_dest_y ? y - p.boarding_dest_y : p.boarding_dest_y - y);
                 sd_e = -(y > p.exiting_dest_y ? y - p.exiting_dest_y : p.exiting_dest_y - y);
             }
-            unsigned lo = nv | (in_area ? 0x10u : 0u) | (at_door ? 0x20u : 0u) |
+            unsigned lo = nv | (in_area ? ccx::kCellInTram : 0u) | (at_door ? ccx::kCellAtDoor : 0u) |
                           ((dest_b ? 1u : 0u) << 8) | (cls_b << 9) | ((dest_e ? 1u : 0u) << 12) |
                           (cls_e << 13) | ((unsigned)x << 16) | ((unsigned)y << 24);
             unsigned hi = ((unsigned)sd_b & 0xFFFFu) | (((unsigned)sd_e & 0xFFFFu) << 16);
@@ -114,7 +114,7 @@ int choose_shape(ccx_handle* h) {
         const size_t msz_ = (glog == 6) ? 8u : 4u;
         auto need = [&](int e) {
             const size_t units_ = (size_t)e * h->N * (3 + 2 * h->N);
-            return up(cells_ * 8u) + up(256u + ccx::kStageBytes + 7u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) +
+            return up(cells_ * 8u) + up(ccx::tile_head_bytes(2) + 7u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) +
                    up((units_ + 2u) * 2u);
         };
         if (need(1) <= 96u * 1024u)
@@ -135,7 +135,7 @@ int choose_shape(ccx_handle* h) {
             const size_t cells_ = (size_t)(h->params.width + 3) * (size_t)(h->params.height + 3);
             const size_t msz_ = (glog == 6) ? 8u : 4u;
             const size_t units_ = (size_t)max_ew * h->N * (3 + 2 * h->N);
-            if (up(cells_ * 8u) + up(256u + ccx::kStageBytes + 2u * 1056u + up((size_t)max_ew * 2u * (cells_ + 1u) * msz_)) +
+            if (up(cells_ * 8u) + up(ccx::tile_head_bytes(2) + 2u * 1056u + up((size_t)max_ew * 2u * (cells_ + 1u) * msz_)) +
                     up((units_ + 2u) * 2u) <= 96u * 1024u) {
                 small_batch = true;
                 ew = max_ew;
@@ -201,23 +201,37 @@ int choose_shape(ccx_handle* h) {
     const size_t occ_bytes = up16((size_t)ew * 2u * (cells + 1u) * msz);
     const size_t table = up16((size_t)(units + 2) * 2u);
     const size_t off_tiles = up16(cells * 8u);
-    const size_t off_ws = 256u + ccx::kStageBytes;              // xch + stage ring
-    const size_t off_occ = off_ws + (size_t)writers * 1056u;    // WSlot per writer
-    size_t tile_stride = up16(off_occ + occ_bytes);
-    size_t total = off_tiles + (size_t)tpb * tile_stride + table;
+    // The hand-off ring takes 8 slots -- unless that costs a CU a resident workgroup: LDS is what bounds the residency of
+    // the big-tile shapes (C5-64: 43 KB per workgroup with 4 KB of ring, four per CU; with 8 KB of ring only three).
+    const size_t lds_cu = 160u * 1024u;
+    size_t off_ws = 0, off_occ = 0, tile_stride = 0, total = 0;
+    uint32_t slots = ccx::kMaxStageSlots;
+    auto lay_out = [&](uint32_t nslots, int tiles_pb, bool with_occ) {
+        off_ws = ccx::tile_head_bytes(nslots);                   // xch + hand-off words + stage ring
+        off_occ = off_ws + (size_t)writers * 1056u;              // WSlot per writer
+        tile_stride = up16(off_occ + (with_occ ? occ_bytes : 0));
+        total = off_tiles + (size_t)tiles_pb * tile_stride + table;
+    };
+    lay_out(2, tpb, true);
     if (h->waves_per_block == 0)        // a default never costs the occupancy tables their LDS
         while (tpb > 1 && total > 96u * 1024u) {
             --tpb;
-            total = off_tiles + (size_t)tpb * tile_stride + table;
+            lay_out(2, tpb, true);
         }
     s.waves_per_block = tpb;
     s.num_blocks = (tiles + tpb - 1) / tpb;
     s.occ = 1;
     if (total > 96u * 1024u) {          // tables too big: all-pairs conflict masks instead
         s.occ = 0;
-        tile_stride = up16(off_occ);
-        total = off_tiles + (size_t)tpb * tile_stride + table;
+        lay_out(2, tpb, false);
     }
+    const size_t fit2 = std::min<size_t>(lds_cu / total, 16u);
+    while (slots > 2u) {
+        lay_out(slots, tpb, s.occ != 0);
+        if (total <= 150u * 1024u && std::min<size_t>(lds_cu / total, 16u) >= fit2) break;
+        slots >>= 1;
+    }
+    lay_out(slots, tpb, s.occ != 0);
     s.lds_bytes = total;
     s.lds_bytes_observe = up16((size_t)tpb * 1056u + table);
 
@@ -233,6 +247,7 @@ int choose_shape(ccx_handle* h) {
     k.off_ws = (uint32_t)off_ws; k.off_occ = (uint32_t)off_occ;
     k.occ_words = s.occ ? (uint32_t)(occ_bytes / 4u) : 0u;
     k.off_table = (uint32_t)(off_tiles + (size_t)tpb * tile_stride);
+    k.stage_slots = slots;
     k.writer_vmcnt = (uint32_t)s.store_throttle;
     k.writer0_small = (h->tun_writer_roles >= 0 ? h->tun_writer_roles != 0 : (small_batch || small_tiles)) && writers >= 2 ? 1u : 0u;
 
@@ -367,8 +382,10 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     // cannot adapt across replays (the slot flip below happens once, at capture time), so such a launch runs
     // at the pace in effect and neither votes nor touches the controller's state.
     ccx::KParams kp = h->kp;
-    // paired hand-offs for launches the kernel will not pace (same condition as in the kernel)
-    kp.hand2 = (kp.pace_state && out.obs && K >= 16) ? 0u : (h->tun_hand2 != 0 ? 1u : 0u);
+    // launches the kernel will not pace hand steps to the writer waves through sequence words (ccx_kernels.h: one
+    // definition of the launch modes for the host and the kernel)
+    const bool writes_obs = out.obs != nullptr;
+    kp.hand_flags = ccx::launch_uses_flags(kp.pace_state != nullptr, writes_obs, K, h->tun_hand2 != 0) ? 1u : 0u;
 #ifdef CCX_LAG_TRACE
     {
         static int* lag_buf = nullptr;
@@ -380,7 +397,7 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
         g_lag_buf = lag_buf;
     }
 #endif
-    const bool adaptive = kp.pace_state && kp.pace_adapt && out.obs && K >= 64;
+    const bool adaptive = ccx::launch_is_adaptive(kp.pace_state != nullptr, kp.pace_adapt != 0u, writes_obs, K);
     bool capturing = false;
     if (adaptive) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;

@@ -49,9 +49,31 @@ __host__ __device__ inline uint32_t explore_action(uint32_t u, uint32_t free_dir
     return (uint32_t)__builtin_ctz(vm);
 #endif
 }
-// hand-off ring between the sim wave and the writer waves of a tile: slots of 64 x 16 bytes; a hand-off of two env-steps
-// at once (KParams::hand2) needs four slots
-constexpr uint32_t kStageSlots = 4, kStageBytes = kStageSlots * 1024u;
+// Per-tile LDS head (byte offsets from the tile's base): [xch u32 x 64][hand-off words u32 x 16][stage ring].
+// Hand-off ring between the sim wave and the writer waves of a tile: slots of 64 x 16 bytes.  In flags mode
+// (KParams::hand_flags) word kSyncSeq counts the env-steps the sim wave has staged and word kSyncProg + w the env-steps
+// writer w has read; neither side ever meets the other at a barrier.
+// The ring has KParams::stage_slots slots (8, or 4 / 2 where 8 would cost a workgroup per CU its LDS).
+constexpr uint32_t kMaxStageSlots = 8, kStageSlotBytes = 1024u;
+constexpr uint32_t kSyncOff = 256u, kSyncBytes = 64u, kStageOff = kSyncOff + kSyncBytes;
+constexpr uint32_t tile_head_bytes(uint32_t stage_slots) { return kStageOff + stage_slots * kStageSlotBytes; }
+constexpr uint32_t kSyncSeq = 0u, kSyncProg = 4u;          // (kSyncProg + writer index, at most 7 writers)
+// bits of the low word of a cell's geometry entry (ccx_kernels.hip: per-cell geometry table); bit 4 is always 0
+constexpr uint32_t kCellInTram = 0x20u, kCellAtDoor = 0x40u;
+
+// ONE definition of how a launch is driven, shared by the host (run_rollout) and the kernel: a launch is PACED when the
+// handle paces its shape, it writes observation rows and is long enough to be worth the clock reads; the pace controller
+// ADAPTS (votes, slot flip on the host) only in paced launches of at least 64 steps; launches that are not paced hand
+// steps from the sim wave to the writer waves through sequence words instead of a barrier per step (tunable "hand2").
+__host__ __device__ inline bool launch_is_paced(bool handle_paces, bool writes_obs, int K) {
+    return handle_paces && writes_obs && K >= 16;
+}
+__host__ __device__ inline bool launch_is_adaptive(bool handle_paces, bool handle_adapts, bool writes_obs, int K) {
+    return launch_is_paced(handle_paces, writes_obs, K) && handle_adapts && K >= 64;
+}
+__host__ __device__ inline bool launch_uses_flags(bool handle_paces, bool writes_obs, int K, bool tunable_on) {
+    return tunable_on && !launch_is_paced(handle_paces, writes_obs, K);
+}
 enum : uint32_t { CCX_K_EF_ALL_TERM = 1u, CCX_K_EF_ALL_TRUNC = 2u, CCX_K_EF_RESET = 4u };
 
 // kernel parameters (passed by value; lives in SGPRs / the kernarg segment)
@@ -86,7 +108,8 @@ struct KParams {
     long long pool_stride;               // cursor stride: total_envs mod pool_size, 1 when that is 0
     // tunables (ccx_set_tunable): how the tiles' step schedules are phased, how workgroups map to tiles
     uint32_t pace_phase, tile_map;
-    uint32_t hand2;                      // 1: one sim -> writer hand-off barrier per two env-steps (unpaced launches)
+    uint32_t stage_slots;                // slots of the sim -> writer hand-off ring (a power of two, 2..8)
+    uint32_t hand_flags;                 // 1: sequence-word hand-off between sim and writer waves (unpaced launches), 0: one barrier per step
     uint32_t writer0_small;              // 1: writer 0 writes the small outputs only, writers 1.. the observation rows
     uint32_t rng_lo, rng_hi;             // seed of CCX_POLICY_RANDOM and of the epsilon draws (ccx_set_rng_seed)
     uint32_t eps_thr;                    // epsilon * 2^32 of the scripted policies (ccx_set_policy_epsilon), 0 = greedy

@@ -41,6 +41,7 @@
 // Everything is integer / index work; the only floating-point operation on the path is ONE f64
 // multiply per reward (compiled with -ffp-contract=off).  No MFMA on purpose.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "ccx_kernels.h"
@@ -164,7 +165,7 @@ template <typename T> __device__ __forceinline__ T in_vgpr(T v) {
 
 // LDS tiles.  WSlot: what a wave that writes observation rows gathers from (one per writer wave /
 // per wave of the observe kernel).  The rollout kernel's per-tile carve-up (byte offsets in
-// KParams): [xch u32 x 64][stage uint4 x 4 x 64][WSlot x writers][occ | prp masks x EW x (cells+1)].
+// KParams): [xch u32 x 64][hand-off words u32 x 16][stage uint4 x 8 x 64][WSlot x writers][{occ, prp} masks x (cells+1) x EW].
 struct WSlot {
     float4 slot[64];   // (x, y, type, active) of the agent on each lane, as floats
     float cst[8];      // (door_centre, division_y) (door_left, door_right) (-1,-1) pad
@@ -248,7 +249,8 @@ constexpr int kObsBatch = 5;       // LDS reads issued back to back before their
 // (cell = (y+1)*(W+3) + (x+1)) and copied to LDS at kernel start:
 //   lo: bits 0-3  move a (right, up, left, down) from this cell lands on a cell that is in the
 //                 grid and not a wall                       (collectivecrossing.py:509-534)
-//       bit4 IN_TRAM_AREA (:551-554)  bit5 AT_DOOR (:556-563)       -- same bits as CCX_AF_*
+//       bit4 = 0 always (the "legality bit" of action 4 = wait: `(lo >> a) & 1` needs no clamp)
+//       bit5 IN_TRAM_AREA (:551-554)  bit6 AT_DOOR (:556-563)       -- CCX_AF_* bits 4/5, shifted up by one
 //       bit8  boarding: on destination row (:663-683)   bits 9-10  boarding reward class
 //       bit12 exiting:  on destination row              bits 13-14 exiting reward class
 //       byte2 = x, byte3 = y  (0 for border cells)
@@ -258,8 +260,9 @@ constexpr int kObsBatch = 5;       // LDS reads issued back to back before their
 // so the legality of a move is a bit test; the word of the proposed cell is fetched off the
 // critical path and only consumed once the move is known to happen.
 //
-// sim -> writer hand-off (uint4 per lane and step): x = cell lo, y = cell hi, z = the CCX_AF_*
-// byte of the agent, w = the CCX_EF_* byte of its env.
+// sim -> writer hand-off (uint4 per lane and step): x = cell lo, y = cell hi, z = the CCX_AF_* bits the writer
+// cannot derive from the cell word (terminated, truncated, live, obs, active) | chosen action << 8, w = the CCX_EF_*
+// byte of its env.
 
 // ---------------------------------------------------------------------------------------------
 // the fused rollout / step kernel.
@@ -276,6 +279,34 @@ constexpr int kObsBatch = 5;       // LDS reads issued back to back before their
 #else
 #define CCX_T(q) do { } while (0)
 #endif
+
+// The tail of the rollout kernels' argument list as it lies in the kernel-argument segment (AMDGPU ABI: by-value
+// arguments in declaration order, each at its natural alignment): the epilogue re-reads the state / counter pointers
+// from there instead of carrying them through the step loop.  tests/test_kernel_resources.py checks these offsets
+// against the `.args` metadata of the built code objects.
+struct KernargTail {
+    KState st;                                   // argument 1
+    const unsigned long long* cell_info;         // 2
+    const uint8_t* actions;                      // 3
+    const uint8_t* order;                        // 4
+    int K, auto_reset;                           // 5, 6
+    const uint8_t* pool;                         // 7
+    KOut out;                                    // 8
+    unsigned long long* counters;                // 9
+};
+static_assert(sizeof(KParams) % 8 == 0 && alignof(KParams) == 8 && alignof(KState) == 8, "kernarg layout");
+static_assert(offsetof(KernargTail, counters) == sizeof(KState) + 3 * 8 + 8 + 8 + sizeof(KOut), "kernarg layout");
+typedef __attribute__((address_space(4))) const KernargTail KernargTailC;     // (the constant address space: scalar loads)
+__device__ __forceinline__ KernargTailC& rollout_kernarg_tail() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const char kchar;
+    kchar* base = (kchar*)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(KernargTailC*)(base + sizeof(KParams));
+#else
+    static KernargTail host_dummy{};   // (device-only; the host pass just needs the declaration)
+    return *(KernargTailC*)(uintptr_t)&host_dummy;
+#endif
+}
 
 // template parameters of the kernel (its body: ccx_rollout_body.inc):
 //   PLAIN  the caller passed neither a move order nor a policy (the bench line, plain RL stepping): the step
@@ -479,14 +510,29 @@ static int blocks_per_cu_g(const LaunchShape& ls, bool pair) {
 int rollout_blocks_per_cu(const LaunchShape& ls, int agents) {
     const bool pair = (agents % 2) == 0;
     switch (ls.glog) {
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 0
     case 0: return blocks_per_cu_g<0>(ls, pair);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 1
     case 1: return blocks_per_cu_g<1>(ls, pair);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 2
     case 2: return blocks_per_cu_g<2>(ls, pair);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 3
     case 3: return blocks_per_cu_g<3>(ls, pair);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 4
     case 4: return blocks_per_cu_g<4>(ls, pair);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 5
     case 5: return blocks_per_cu_g<5>(ls, pair);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 6
     default: return blocks_per_cu_g<6>(ls, pair);
+#endif
     }
+    return 0;
 }
 
 template <int GLOG>
@@ -507,13 +553,27 @@ hipError_t launch_rollout(const LaunchShape& ls, hipStream_t stream, const KPara
                           int auto_reset, const uint8_t* pool, const KOut& out,
                           unsigned long long* counters, int policy, uint8_t* actions_out) {
     switch (ls.glog) {
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 0
     case 0: return launch_rollout_g<0>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 1
     case 1: return launch_rollout_g<1>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 2
     case 2: return launch_rollout_g<2>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 3
     case 3: return launch_rollout_g<3>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 4
     case 4: return launch_rollout_g<4>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 5
     case 5: return launch_rollout_g<5>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 6
     case 6: return launch_rollout_g<6>(ls, stream, p, st, cell_info, actions, order, K, auto_reset, pool, out, counters, policy, actions_out);
+#endif
     }
     return hipErrorInvalidValue;
 }
@@ -521,13 +581,27 @@ hipError_t launch_rollout(const LaunchShape& ls, hipStream_t stream, const KPara
 static hipError_t launch_observe_any(const LaunchShape& ls, hipStream_t stream, const KParams& p, const KState& st,
                                      float* obs, const float4* compact, unsigned blocks) {
     switch (ls.glog) {
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 0
     case 0: return launch_observe_g<0>(ls, stream, p, st, obs, compact, blocks);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 1
     case 1: return launch_observe_g<1>(ls, stream, p, st, obs, compact, blocks);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 2
     case 2: return launch_observe_g<2>(ls, stream, p, st, obs, compact, blocks);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 3
     case 3: return launch_observe_g<3>(ls, stream, p, st, obs, compact, blocks);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 4
     case 4: return launch_observe_g<4>(ls, stream, p, st, obs, compact, blocks);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 5
     case 5: return launch_observe_g<5>(ls, stream, p, st, obs, compact, blocks);
+#endif
+#if !defined(CCX_ONLY_GLOG) || CCX_ONLY_GLOG == 6
     case 6: return launch_observe_g<6>(ls, stream, p, st, obs, compact, blocks);
+#endif
     }
     return hipErrorInvalidValue;
 }

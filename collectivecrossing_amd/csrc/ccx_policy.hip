@@ -39,7 +39,7 @@ __global__ void greedy_actions_kernel(const KParams p, const KState st,
     uint32_t cand = greedy_candidates(p, i < p.Nb, cx, cy);
     const size_t base = (size_t)env * p.N;
     bool waits = false;
-    if (policy == CCX_K_POLICY_WAITING && i < p.Nb && !(cw & 0x10u)) {   // waiting_policy.py:92-100
+    if (policy == CCX_K_POLICY_WAITING && i < p.Nb && !(cw & kCellInTram)) {   // waiting_policy.py:92-100
         for (int b = p.Nb; b < p.N; ++b)                                  // :119-129
             waits |= !(st.terminated[base + b] || st.truncated[base + b]) && st.y[base + b] != p.edy;
     }

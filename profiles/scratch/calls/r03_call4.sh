@@ -1,0 +1,27 @@
+#!/bin/bash
+set -e
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r03_c5
+mkdir -p $OUT
+cd $ROOT
+export CCX_PACE_CACHE=$OUT/pace_cache.json
+for E in 4096 2048 1024; do timeout -k 10 120 python3 profiles/diag_stamps.py 0 0 $E >> $OUT/stamps.txt 2>&1; done
+grep -v amdgpu.ids $OUT/stamps.txt
+for E in 4096 2048 1024; do timeout -k 10 120 python3 profiles/scratch/sim_only.py $E >> $OUT/sim_only.txt 2>&1; done; grep -v amdgpu.ids $OUT/sim_only.txt
+for P in 380 420; do timeout -k 10 120 python3 bench.py --no-cpu-baseline --no-secondary --envs-per-gpu 2048 --pace $P > $OUT/c2_2048_p$P.json 2>> $OUT/err.txt; done
+timeout -k 10 120 python3 bench.py --no-cpu-baseline --no-secondary --envs-per-gpu 3072 > $OUT/c2_3072.json 2>> $OUT/err.txt
+timeout -k 10 120 python3 bench.py --no-cpu-baseline --no-secondary --envs-per-gpu 1024 > $OUT/c2_1024.json 2>> $OUT/err.txt
+timeout -k 10 120 python3 bench.py --no-cpu-baseline --workload c5_64 --policy greedy --chunk 100 --steps 24 --warmup 24 --pool 512 > $OUT/c5_64.json 2>> $OUT/err.txt
+timeout -k 10 120 python3 bench.py --no-cpu-baseline --workload c5_50 --policy greedy --chunk 100 --steps 24 --warmup 24 --pool 512 > $OUT/c5_50.json 2>> $OUT/err.txt
+timeout -k 10 120 python3 bench.py --no-cpu-baseline --workload c3 --chunk 100 --steps 24 --warmup 24 --pool 512 > $OUT/c3.json 2>> $OUT/err.txt
+timeout -k 10 120 python3 bench.py --no-cpu-baseline --workload c3 --compact-obs --chunk 100 --steps 24 --warmup 24 --pool 512 > $OUT/c3_compact.json 2>> $OUT/err.txt
+timeout -k 10 120 python3 bench.py --no-cpu-baseline --workload c5_64 --policy greedy --compact-obs --chunk 100 --steps 24 --warmup 24 --pool 512 > $OUT/c5_64_compact.json 2>> $OUT/err.txt
+python3 - <<PY
+import json, glob
+for f in sorted(glob.glob("$OUT/*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split("/")[-1], f"{d['value']:.4g}", f"frac {d['roofline']['frac']:.3f}", f"ms/launch {d['roofline']['kernel_ms_per_launch']:.4f}", "us/step %.4f" % (d['config']['ms_per_env_step']*1e3))
+    except Exception as e:
+        print(f, "ERR", e)
+PY

@@ -91,6 +91,29 @@ __global__ void __launch_bounds__(256) k(unsigned long long* out, uint32_t seed,
                          : "+v"(x) : "v"((lane >> 3) * 4), "v"(y) : "v40", "v41", "memory"); T1; break;
     case 29:  // dependent s_add (SALU chain)
         T0; asm volatile(".rept " STR(REP) "\n s_add_u32 s20, s20, 1\n .endr" ::: "s20", "scc"); T1; break;
+    case 30:  // one VALU + one independent SALU per copy: do they share the wave's issue slots?
+        T0; asm volatile(".rept " STR(REP) "\n v_add_u32 %0, %0, %1\n s_add_u32 s20, s20, 1\n .endr" : "+v"(x) : "v"(y) : "s20", "scc"); T1; break;
+    case 31:  // one VALU + three independent SALU per copy
+        T0; asm volatile(".rept " STR(REP) "\n v_add_u32 %0, %0, %1\n s_add_u32 s20, s20, 1\n s_bcnt1_i32_b64 s21, s[22:23]\n s_add_u32 s24, s24, s21\n .endr"
+                         : "+v"(x) : "v"(y) : "s20", "s21", "s24", "scc"); T1; break;
+    case 32:  // SALU-only branch, not taken, operands ready
+        T0; asm volatile(".rept " STR(REP) "\n s_cmp_eq_u32 s20, 63\n s_cbranch_scc1 1f\n v_add_u32 %0, %0, %1\n1:\n .endr" : "+v"(x) : "v"(y) : "s20", "scc"); T1; break;
+    case 33:  // ds_read_b64 chase, 8-byte aligned addresses
+        T0; asm volatile(".rept " STR(REP) "\n ds_read_b64 v[40:41], %0\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0x3ff8, v40\n .endr" : "+v"(z) :: "v40", "v41"); T1; x = z; break;
+    case 34:  // ds_write_b128 (distinct) + ds_write_b32 to ONE word from all lanes, issue only
+        T0; asm volatile(".rept " STR(REP) "\n ds_write_b128 %0, v[40:43]\n ds_write_b32 %1, v40\n .endr" :: "v"(z * 4), "v"(16384u) : "v40", "v41", "v42", "v43", "memory"); T1; break;
+    case 35:  // the occupancy round trip with 12 independent VALU ops issued in its shadow
+        T0; asm volatile(".rept " STR(REP) "\n ds_or_b32 %1, %2\n ds_or_b32 %1, %2 offset:8192\n ds_read_b32 v40, %1\n ds_read_b32 v41, %1 offset:8192\n"
+                         " .rept 12\n v_add_u32 %3, %3, %2\n .endr\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, v40, v41\n .endr"
+                         : "+v"(x) : "v"(z), "v"(y), "v"(a1) : "v40", "v41", "memory"); T1; break;
+    case 36:  // v_cmp -> sgpr, 6 independent VALU, then s_cmp + branch (deferred test)
+        T0; asm volatile(".rept " STR(REP) "\n v_cmp_ne_u32 s[20:21], -1, %0\n .rept 6\n v_add_u32 %2, %2, %1\n .endr\n s_cmp_eq_u64 s[20:21], 0\n s_cbranch_scc1 1f\n v_add_u32 %0, %0, %1\n1:\n .endr"
+                         : "+v"(x) : "v"(y), "v"(a1) : "s20", "s21", "scc"); T1; break;
+    case 37:  // 7 dependent VALU (the cost of the 6 fillers + 1 of case 36, for comparison)
+        T0; asm volatile(".rept " STR(REP) "\n .rept 7\n v_add_u32 %0, %0, %1\n .endr\n .endr" : "+v"(x) : "v"(y)); T1; break;
+    case 38:  // ds_read_b128 of own slot + ds_read_b32 broadcast poll
+        T0; asm volatile(".rept " STR(REP) "\n ds_read_b32 v44, %1\n s_waitcnt lgkmcnt(0)\n v_readfirstlane_b32 s20, v44\n s_cmp_lg_u32 s20, 63\n s_cbranch_scc0 1f\n ds_read_b128 v[40:43], %0\n s_waitcnt lgkmcnt(0)\n1:\n .endr"
+                         :: "v"(z * 4), "v"(16384u) : "v40", "v41", "v42", "v43", "v44", "s20", "scc", "memory"); T1; break;
     }
     if (lane == 0) out[which * 8 + (threadIdx.x >> 6)] = t1 - t0;
     if (x == 0x12345678u) out[1000] = x;   // keep results alive
@@ -104,7 +127,10 @@ int main() {
         "v_readfirstlane -> s_add -> v_add", "s_nop 1 + v_add dpp quad_perm", "ds_bpermute + wait", "s_memrealtime + wait", "dep v_perm_b32",
         "ds_write_b128 + ds_write_b32 issue", "global_store_dwordx4 nt issue", "global_store_dwordx2 + byte issue",
         "v_cmp + saveexec + cbranch_execz taken + restore + 1 v_add", "v_cvt_f64_i32 + v_mul_f64 + mov", "dep v_lshl_add_u32",
-        "v_cmp sgpr -> v_cndmask(sgpr)", "dep v_add_u32_sdwa sext", "ds_or x2 + reads, 8-way same word", "dep s_add_u32"};
+        "v_cmp sgpr -> v_cndmask(sgpr)", "dep v_add_u32_sdwa sext", "ds_or x2 + reads, 8-way same word", "dep s_add_u32",
+        "v_add + indep s_add", "v_add + 3 indep SALU", "s_cmp + s_cbranch_scc nt (ready) + v_add", "ds_read_b64 chase aligned + and",
+        "ds_write_b128 + same-word ds_write_b32 issue", "occupancy round trip + 12 VALU in shadow", "v_cmp, 6 VALU, s_cmp + branch nt + v_add",
+        "7 dep VALU", "poll word + readfirstlane + branch + ds_read_b128"};
     const int ncase = sizeof(names) / sizeof(names[0]);
     unsigned long long* d;
     hipMalloc(&d, 1 << 20);

@@ -44,6 +44,44 @@ def _kernels(tmp_path):
     return out
 
 
+def test_kernarg_tail_offsets_match_the_code_objects(tmp_path):
+    """The rollout kernels' epilogue re-reads the state / counter pointers from the kernel-argument segment
+    (ccx_kernels.hip: KernargTail: declaration order, natural alignment).  The `.args` metadata of the built code objects
+    says where every argument really lies: KState directly behind KParams, `counters` where the struct puts it."""
+    so = ROOT / "collectivecrossing_amd" / "libccx.so"
+    if not so.exists() or not (LLVM / "clang-offload-bundler").exists() or not shutil.which("objcopy"):
+        pytest.skip("libccx.so or the ROCm LLVM tools are not available")
+    fat = tmp_path / "fat.bin"
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", str(so), str(fat)], check=True)
+    blob = fat.read_bytes()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+    checked = 0
+    for n, a in enumerate(starts):
+        part = tmp_path / f"kb{n}.bin"
+        part.write_bytes(blob[a:starts[n + 1] if n + 1 < len(starts) else len(blob)])
+        co = tmp_path / f"kb{n}.co"
+        r = subprocess.run([str(LLVM / "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={part}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], capture_output=True, text=True)
+        if r.returncode or not co.exists() or co.stat().st_size == 0:
+            continue
+        notes = subprocess.run([str(LLVM / "llvm-readelf"), "--notes", str(co)], capture_output=True, text=True).stdout
+        for block in notes.split("  - .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block)
+            if not name or "rollout_kernel" not in name.group(1):
+                continue
+            args_txt = block.split(".group_segment_fixed_size")[0]
+            args = [(int(o), int(z)) for o, z in re.findall(r"\.offset:\s+(\d+)\s+\.size:\s+(\d+)", args_txt)]
+            explicit = [a_ for a_ in args][:12]
+            assert len(explicit) == 12, (name.group(1), args)
+            kp_size = explicit[0][1]
+            assert explicit[0][0] == 0 and kp_size % 8 == 0
+            assert explicit[1] == (kp_size, 56)                           # KState: 7 pointers, directly behind KParams
+            # cell_info, actions, order (8 each), K, auto_reset (4 each), pool (8), KOut (5 pointers), counters
+            assert explicit[9][0] == kp_size + 56 + 24 + 8 + 8 + 40 and explicit[9][1] == 8, (name.group(1), explicit)
+            checked += 1
+    assert checked >= 100
+
+
 def test_rollout_kernels_fit_sixteen_wavefronts_per_cu(tmp_path):
     ks = {k: v for k, v in _kernels(tmp_path).items() if "rollout_kernel" in k}
     assert len(ks) >= 100, sorted(ks)[:5]          # 7 lane-group sizes x PAIR x OUTM x OCC x PLAIN
