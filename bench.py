@@ -329,6 +329,8 @@ def parse_args(argv=None):
     ap.add_argument("--direct-rccl", action="store_true",
                     help="reduce the counters with ccx_rccl_allreduce_counters (RCCL through the C-ABI) instead of "
                          "torch.distributed")
+    ap.add_argument("--tunable", action="append", default=[], metavar="NAME=VALUE",
+                    help="diagnostic: ccx_set_tunable(NAME, VALUE) on the handle (repeatable)")
     ap.add_argument("--rehearse", action="store_true", help="N>1 plumbing only, no env stepping (CPU-runnable)")
     return ap.parse_args(argv)
 
@@ -406,6 +408,8 @@ def run_rank(args) -> int:
         env.set_store_throttle(args.throttle)
     if args.pace:
         env.set_step_pace(args.pace)
+    for kv in args.tunable:
+        env.set_tunable(kv.split("=")[0], int(kv.split("=")[1]))
     if args.epsilon:
         env.set_rng_seed(1234 + rank)
         env.set_policy_epsilon(args.epsilon)

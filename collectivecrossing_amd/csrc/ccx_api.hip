@@ -114,7 +114,7 @@ int choose_shape(ccx_handle* h) {
         const size_t msz_ = (glog == 6) ? 8u : 4u;
         auto need = [&](int e) {
             const size_t units_ = (size_t)e * h->N * (3 + 2 * h->N);
-            return up(cells_ * 8u) + up(ccx::tile_head_bytes(2) + 7u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) +
+            return up(cells_ * 8u) + up(ccx::tile_head_bytes(16) + 7u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) +
                    up((units_ + 2u) * 2u);
         };
         if (need(1) <= 96u * 1024u)
@@ -135,7 +135,7 @@ int choose_shape(ccx_handle* h) {
             const size_t cells_ = (size_t)(h->params.width + 3) * (size_t)(h->params.height + 3);
             const size_t msz_ = (glog == 6) ? 8u : 4u;
             const size_t units_ = (size_t)max_ew * h->N * (3 + 2 * h->N);
-            if (up(cells_ * 8u) + up(ccx::tile_head_bytes(2) + 2u * 1056u + up((size_t)max_ew * 2u * (cells_ + 1u) * msz_)) +
+            if (up(cells_ * 8u) + up(ccx::tile_head_bytes(16) + 2u * 1056u + up((size_t)max_ew * 2u * (cells_ + 1u) * msz_)) +
                     up((units_ + 2u) * 2u) <= 96u * 1024u) {
                 small_batch = true;
                 ew = max_ew;
@@ -152,7 +152,8 @@ int choose_shape(ccx_handle* h) {
     // Larger tiles: 2-3 writers, no throttle (measured: no effect).
     const bool small_tiles = n4 <= 64 * 12;
     // small batches: writer 0 = small outputs, the others share the observation rows (KParams::writer0_small);
-    // three writers while 4 waves x tiles still fit the 1024 SIMDs (2048-env C2: 0.54 -> 0.485 us per step)
+    // three writers while 4 waves x tiles still fit the 1024 SIMDs (2048-env C2: 0.54 -> 0.485 us per step); round 3, with
+    // the sim chain at 0.27 us: four writers up to ~280 tiles (2048-env C2 0.773 -> 0.791 of the peak, 1024 envs 0.39 -> 0.41)
     // Small tiles beyond that (C2's 4096 x 8: 9.5 store iterations per tile and step): TWO writers split by role
     // as well, as long as 3 waves per tile fit one round (16 wavefronts per CU).  With everything on one writer
     // that wave had 1580 clocks of work per step next to the sim's 1200 and held the tile at ~0.72 us per step --
@@ -160,7 +161,7 @@ int choose_shape(ccx_handle* h) {
     // ~0.70 us: 0.86 -> 0.92 of the HBM peak in one call (round 2; round 1 measured two writers as no gain,
     // but its sim wave was 20 % slower and hid the difference).
     int writers = h->writers > 0 ? h->writers
-                  : small_batch ? ((long long)tiles * 4 <= 1100 ? 3 : 2)
+                  : small_batch ? ((long long)tiles * 5 <= 1400 ? 4 : (long long)tiles * 4 <= 1100 ? 3 : 2)
                   : n4 > 64 * 24 ? 3
                   : small_tiles ? ((long long)tiles * 3 <= 16ll * h->num_cus ? 2 : 1) : 2;
     if (writers > 7) writers = 7;
@@ -201,8 +202,10 @@ int choose_shape(ccx_handle* h) {
     const size_t occ_bytes = up16((size_t)ew * 2u * (cells + 1u) * msz);
     const size_t table = up16((size_t)(units + 2) * 2u);
     const size_t off_tiles = up16(cells * 8u);
-    // The hand-off ring takes 8 slots -- unless that costs a CU a resident workgroup: LDS is what bounds the residency of
-    // the big-tile shapes (C5-64: 43 KB per workgroup with 4 KB of ring, four per CU; with 8 KB of ring only three).
+    // The hand-off ring takes 32 slots (8 KB) -- or 16 where that costs a CU a resident workgroup: LDS is what bounds the
+    // residency of the big-tile shapes (C5-64: 40 KB per workgroup with 4 KB of ring, four per CU; with 8 KB only three).
+    // (The sim wave proves "slot free" from a progress value it reads once per 16-step burst: 16 slots are the minimum
+    // for which that stale value suffices almost always.)
     const size_t lds_cu = 160u * 1024u;
     size_t off_ws = 0, off_occ = 0, tile_stride = 0, total = 0;
     uint32_t slots = ccx::kMaxStageSlots;
@@ -212,25 +215,22 @@ int choose_shape(ccx_handle* h) {
         tile_stride = up16(off_occ + (with_occ ? occ_bytes : 0));
         total = off_tiles + (size_t)tiles_pb * tile_stride + table;
     };
-    lay_out(2, tpb, true);
+    lay_out(16, tpb, true);
     if (h->waves_per_block == 0)        // a default never costs the occupancy tables their LDS
         while (tpb > 1 && total > 96u * 1024u) {
             --tpb;
-            lay_out(2, tpb, true);
+            lay_out(16, tpb, true);
         }
     s.waves_per_block = tpb;
     s.num_blocks = (tiles + tpb - 1) / tpb;
     s.occ = 1;
     if (total > 96u * 1024u) {          // tables too big: all-pairs conflict masks instead
         s.occ = 0;
-        lay_out(2, tpb, false);
+        lay_out(16, tpb, false);
     }
-    const size_t fit2 = std::min<size_t>(lds_cu / total, 16u);
-    while (slots > 2u) {
-        lay_out(slots, tpb, s.occ != 0);
-        if (total <= 150u * 1024u && std::min<size_t>(lds_cu / total, 16u) >= fit2) break;
-        slots >>= 1;
-    }
+    const size_t fit16 = std::min<size_t>(lds_cu / total, 16u);
+    lay_out(slots, tpb, s.occ != 0);
+    if (total > 150u * 1024u || std::min<size_t>(lds_cu / total, 16u) < fit16) slots = 16;
     lay_out(slots, tpb, s.occ != 0);
     s.lds_bytes = total;
     s.lds_bytes_observe = up16((size_t)tpb * 1056u + table);
@@ -353,6 +353,32 @@ int* g_lag_buf = nullptr;
 
 int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* order, int auto_reset,
                 const ccx::KOut& out, int policy = 0, uint8_t* actions_out = nullptr) {
+    // The writer waves address the small output streams (rewards, flag bytes, compact rows, chosen actions) with 32-bit
+    // byte offsets from the stream's base: one launch must stay below 4 GiB per stream.  Longer rollouts are cut into
+    // launches on the same stream (bit-identical: an env's trajectory does not depend on how a rollout is split).
+    {
+        const unsigned long long per_step = (unsigned long long)h->E * (unsigned long long)h->N * 16ull;   // the widest stream
+        const unsigned long long fit = 0xFFFFFFFFull / per_step;
+        int max_k = (int)std::min<unsigned long long>(fit > 1 ? fit - 1 : 1, 0x7FFFFFFFull);
+        if (h->tun_max_launch_steps > 0) max_k = std::min(max_k, h->tun_max_launch_steps);   // (tests: force the cut)
+        if (K > max_k) {
+            const size_t EN = (size_t)h->E * h->N, L = (size_t)(6 + 4 * h->N);
+            for (int k0 = 0; k0 < K; k0 += max_k) {
+                const int kk = std::min(max_k, K - k0);
+                ccx::KOut o = out;
+                if (o.obs) o.obs += (size_t)k0 * EN * L;
+                if (o.reward) o.reward += (size_t)k0 * EN;
+                if (o.agent_flags) o.agent_flags += (size_t)k0 * EN;
+                if (o.env_flags) o.env_flags += (size_t)k0 * (size_t)h->E;
+                if (o.obs_compact) o.obs_compact += (size_t)k0 * EN * 4u;
+                const int rc = run_rollout(h, kk, actions ? actions + (size_t)k0 * EN : nullptr,
+                                           order ? order + (size_t)k0 * EN : nullptr, auto_reset, o, policy,
+                                           actions_out ? actions_out + (size_t)k0 * EN : nullptr);
+                if (rc) return rc;
+            }
+            return CCX_OK;
+        }
+    }
     if (out.obs && (reinterpret_cast<uintptr_t>(out.obs) & 15u))
         return fail(CCX_EINVAL, "obs buffer must be 16-byte aligned");
     if (out.reward && (reinterpret_cast<uintptr_t>(out.reward) & 7u))
@@ -385,7 +411,7 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     // launches the kernel will not pace hand steps to the writer waves through sequence words (ccx_kernels.h: one
     // definition of the launch modes for the host and the kernel)
     const bool writes_obs = out.obs != nullptr;
-    kp.hand_flags = ccx::launch_uses_flags(kp.pace_state != nullptr, writes_obs, K, h->tun_hand2 != 0) ? 1u : 0u;
+    kp.hand_flags = ccx::launch_uses_flags(kp.pace_state != nullptr, writes_obs, K, h->tun_hand2) ? 1u : 0u;
 #ifdef CCX_LAG_TRACE
     {
         static int* lag_buf = nullptr;
@@ -883,8 +909,9 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
     struct { const char* name; int* slot; int lo, hi; } table[] = {
         {"pace_phase", &h->tun_pace_phase, -1, 3},
         {"tile_map", &h->tun_tile_map, -1, 6},
-        {"hand2", &h->tun_hand2, 0, 1},
+        {"hand2", &h->tun_hand2, 0, 2},
         {"writer_roles", &h->tun_writer_roles, -1, 1},
+        {"max_launch_steps", &h->tun_max_launch_steps, 0, 0x7FFFFFFF},
     };
     for (auto& t : table)
         if (strcmp(name, t.name) == 0) {
@@ -893,7 +920,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
             *t.slot = value;
             return choose_shape(h);
         }
-    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, hand2, writer_roles)", name);
+    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, hand2, writer_roles, max_launch_steps)", name);
 }
 
 int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {

@@ -10,7 +10,8 @@ namespace ccx {
 
 // (primary action, preference list) of the greedy rule: returns 5 candidate actions packed 4 bits
 // each, candidate 0 first; candidate 4 is always "wait"
-__device__ __forceinline__ uint32_t greedy_candidates(const KParams& p, bool boarding, int cx, int cy) {
+template <typename P>   // (KParams by value, or the kernel-argument segment's copy)
+__device__ __forceinline__ uint32_t greedy_candidates(const P& p, bool boarding, int cx, int cy) {
     const int div = p.div, dcx = p.dc;
     const int dest_y = boarding ? p.bdy : p.edy;
     const bool before_door = boarding ? (cy < div) : (cy > div);       // greedy_policy.py:118, :139

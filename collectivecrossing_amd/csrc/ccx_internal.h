@@ -52,7 +52,8 @@ struct ccx_handle {
     float pace_start_ns = 0.0f;                                // > 0: the adaptive controller starts here (ccx_set_step_pace_start)
     int tun_pace_phase = -1, tun_tile_map = -1;                 // -1 = the library's choice for the launch shape
     int tun_writer_roles = -1;                                  // -1 = by batch size, 0 = writers share everything, 1 = writer 0 small outputs only
-    int tun_hand2 = 1;                                          // paired hand-offs in unpaced launches
+    int tun_hand2 = 1;                                          // sim -> writer hand-off: 0 barrier per step, 1 sequence words in unpaced launches, 2 always
+    int tun_max_launch_steps = 0;                               // > 0: cut rollouts into launches of at most this many steps
     bool check_inputs = false;                                 // ccx_set_check_inputs
     unsigned long long* input_errors = nullptr;                // device [2]: bad action bytes, bad order rows
     ccx::LaunchShape shape{};

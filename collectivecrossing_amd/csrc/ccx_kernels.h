@@ -50,11 +50,15 @@ __host__ __device__ inline uint32_t explore_action(uint32_t u, uint32_t free_dir
 #endif
 }
 // Per-tile LDS head (byte offsets from the tile's base): [xch u32 x 64][hand-off words u32 x 16][stage ring].
-// Hand-off ring between the sim wave and the writer waves of a tile: slots of 64 x 16 bytes.  In flags mode
+// Hand-off ring between the sim wave and the writer waves of a tile: slots of 64 words, one per lane (kHw* below).  In flags mode
 // (KParams::hand_flags) word kSyncSeq counts the env-steps the sim wave has staged and word kSyncProg + w the env-steps
 // writer w has read; neither side ever meets the other at a barrier.
-// The ring has KParams::stage_slots slots (8, or 4 / 2 where 8 would cost a workgroup per CU its LDS).
-constexpr uint32_t kMaxStageSlots = 8, kStageSlotBytes = 1024u;
+// The ring has KParams::stage_slots slots (32, or fewer where 32 would cost a workgroup per CU its LDS).
+constexpr uint32_t kMaxStageSlots = 32, kStageSlotBytes = 256u;
+// hand-off word of one agent and step: bits 0-16 LDS address of the agent's cell word (< 2^17: 103 x 103 cells x 8 bytes
+// behind at most a few KB), 17-18 the flags the step raises (terminated, truncated), 19 active, 20-22 the env byte
+// (CCX_EF_*), 23-30 the action taken (CCX_ACTION_ABSENT = 255)
+constexpr uint32_t kHwCellMask = 0x1FFFFu, kHwOut2Shift = 17, kHwActShift = 19, kHwEfShift = 20, kHwActionShift = 23;
 constexpr uint32_t kSyncOff = 256u, kSyncBytes = 64u, kStageOff = kSyncOff + kSyncBytes;
 constexpr uint32_t tile_head_bytes(uint32_t stage_slots) { return kStageOff + stage_slots * kStageSlotBytes; }
 constexpr uint32_t kSyncSeq = 0u, kSyncProg = 4u;          // (kSyncProg + writer index, at most 7 writers)
@@ -71,8 +75,8 @@ __host__ __device__ inline bool launch_is_paced(bool handle_paces, bool writes_o
 __host__ __device__ inline bool launch_is_adaptive(bool handle_paces, bool handle_adapts, bool writes_obs, int K) {
     return launch_is_paced(handle_paces, writes_obs, K) && handle_adapts && K >= 64;
 }
-__host__ __device__ inline bool launch_uses_flags(bool handle_paces, bool writes_obs, int K, bool tunable_on) {
-    return tunable_on && !launch_is_paced(handle_paces, writes_obs, K);
+__host__ __device__ inline bool launch_uses_flags(bool handle_paces, bool writes_obs, int K, int tunable) {
+    return tunable >= 2 || (tunable == 1 && !launch_is_paced(handle_paces, writes_obs, K));   // 0 = never, 1 = unpaced launches, 2 = always
 }
 enum : uint32_t { CCX_K_EF_ALL_TERM = 1u, CCX_K_EF_ALL_TRUNC = 2u, CCX_K_EF_RESET = 4u };
 

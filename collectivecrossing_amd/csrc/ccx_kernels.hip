@@ -184,7 +184,8 @@ __device__ __forceinline__ void build_obs_table(uint16_t* table, const KParams& 
     for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
 }
 
-__device__ __forceinline__ void init_wave_consts(WaveLds* wl, const KParams& p, int lane) {
+template <typename P>   // (KParams by value, or the kernel-argument segment's copy)
+__device__ __forceinline__ void init_wave_consts(WaveLds* wl, const P& p, int lane) {
     if (lane < 8) {
         float v = -1.0f;
         if (lane == 0) v = (float)p.dc;
@@ -293,10 +294,25 @@ struct KernargTail {
     const uint8_t* pool;                         // 7
     KOut out;                                    // 8
     unsigned long long* counters;                // 9
+    int policy;                                  // 10
+    uint8_t* actions_out;                        // 11
 };
 static_assert(sizeof(KParams) % 8 == 0 && alignof(KParams) == 8 && alignof(KState) == 8, "kernarg layout");
 static_assert(offsetof(KernargTail, counters) == sizeof(KState) + 3 * 8 + 8 + 8 + sizeof(KOut), "kernarg layout");
 typedef __attribute__((address_space(4))) const KernargTail KernargTailC;     // (the constant address space: scalar loads)
+// The kernel parameters themselves are read the same way: `p` in the kernel body is a reference into the kernel-argument
+// segment, not the by-value argument.  62 dwords of KParams preloaded into SGPRs at kernel entry and held until their
+// last use were most of the 60-150 SGPR spills of the rollout kernels; a field is now a scalar load next to its use (or
+// hoisted in front of the loop that needs it), and the register allocator re-loads instead of spilling.
+typedef __attribute__((address_space(4))) const KParams KParamsC;
+__device__ __forceinline__ KParamsC& rollout_kernarg_params() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(KParamsC*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    static KParams host_dummy{};
+    return *(KParamsC*)(uintptr_t)&host_dummy;
+#endif
+}
 __device__ __forceinline__ KernargTailC& rollout_kernarg_tail() {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(4))) const char kchar;
@@ -323,18 +339,18 @@ __device__ __forceinline__ KernargTailC& rollout_kernarg_tail() {
 // allocator's choices worse (scratch there, or 137-153 VGPRs).
 template <int GLOG, bool PAIR, int OUTM, bool OCC, bool PLAIN>
 __global__ void __launch_bounds__(512)
-rollout_kernel(const KParams p, const KState st, const unsigned long long* __restrict__ cell_info,
-               const uint8_t* __restrict__ actions, const uint8_t* __restrict__ order, const int K,
-               const int auto_reset, const uint8_t* __restrict__ pool, const KOut out,
-               unsigned long long* counters, const int policy_arg, uint8_t* __restrict__ actions_out) {
+rollout_kernel(const KParams p_by_value, const KState st_by_value, const unsigned long long* __restrict__ cell_info_by_value,
+               const uint8_t* __restrict__ actions_by_value, const uint8_t* __restrict__ order_by_value, const int K_by_value,
+               const int auto_reset_by_value, const uint8_t* __restrict__ pool_by_value, const KOut out_by_value,
+               unsigned long long* counters_by_value, const int policy_by_value, uint8_t* __restrict__ actions_out_by_value) {
 #include "ccx_rollout_body.inc"
 }
 template <int GLOG, bool PAIR, int OUTM, bool OCC, bool PLAIN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
-rollout_kernel_v128(const KParams p, const KState st, const unsigned long long* __restrict__ cell_info,
-                    const uint8_t* __restrict__ actions, const uint8_t* __restrict__ order, const int K,
-                    const int auto_reset, const uint8_t* __restrict__ pool, const KOut out,
-                    unsigned long long* counters, const int policy_arg, uint8_t* __restrict__ actions_out) {
+rollout_kernel_v128(const KParams p_by_value, const KState st_by_value, const unsigned long long* __restrict__ cell_info_by_value,
+                    const uint8_t* __restrict__ actions_by_value, const uint8_t* __restrict__ order_by_value, const int K_by_value,
+                    const int auto_reset_by_value, const uint8_t* __restrict__ pool_by_value, const KOut out_by_value,
+                    unsigned long long* counters_by_value, const int policy_by_value, uint8_t* __restrict__ actions_out_by_value) {
 #include "ccx_rollout_body.inc"
 }
 template <int GLOG, bool PAIR, int OUTM, bool OCC, bool PLAIN>

@@ -374,8 +374,12 @@ int ccx_set_step_pace_start(ccx_handle* h, float ns_per_env_step);
  *   "writer_roles" 1 = writer wave 0 of a tile writes the small outputs only and the others share the observation
  *                  rows, 0 = every writer takes a share of the rows (writer 0 the small outputs on top), -1 = by
  *                  launch shape (split wherever a tile of at most 12 store iterations per step has two or more writers)
- *   "hand2"        1 (default) = launches that are not paced hand two env-steps at a time from the simulating
- *                  wavefront to the writer wavefronts (one barrier per two steps), 0 = one per step */
+ *   "hand2"        how the simulating wavefront of a tile hands an env-step to its writer wavefronts: 1 (default) = launches
+ *                  that are not paced use a ring of hand-off words with a sequence word and per-writer progress words in
+ *                  LDS (no barrier; paced launches keep one workgroup barrier per step, which regularises their store
+ *                  stream), 0 = a barrier per step always, 2 = the ring always
+ *   "max_launch_steps"  > 0: ccx_rollout cuts a rollout into kernel launches of at most this many env-steps (the library
+ *                  does so by itself where one launch would exceed 4 GiB per small output stream); 0 = automatic */
 int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value);
 /* workgroups of a rollout launch with outputs, and how many of them the device holds at once (a grid
  * larger than that runs in rounds; the pace of a partial last round is scaled accordingly) */

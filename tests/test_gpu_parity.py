@@ -511,7 +511,7 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
            E=st.sampled_from([1, 5, 64, 130, 257]), K=st.integers(1, 48),
            mode=st.sampled_from(["actions", "actions", "greedy", "waiting", "random"]), compact=st.booleans(),
            writers=st.sampled_from([0, 0, 1, 2, 3, 4]), roles=st.sampled_from([-1, -1, 0, 1]),
-           hand2=st.sampled_from([1, 1, 0]), full_tiles=st.booleans(), eps=st.sampled_from([0.0, 0.0, 0.1, 0.5, 1.0]))
+           hand2=st.sampled_from([1, 1, 0, 2]), full_tiles=st.booleans(), eps=st.sampled_from([0.0, 0.0, 0.1, 0.5, 1.0]))
     def run(cfg, seed, E, K, mode, compact, writers, roles, hand2, full_tiles, eps):
         p = lower_config(cfg)
         N = p.num_boarding + p.num_exiting

@@ -90,7 +90,7 @@ def test_full_size_c3_shuffled_orders_equal_the_oracle(oracle, ccx):
 
 
 @pytest.mark.parametrize("knobs", [{"pace_phase": 0, "tile_map": 0}, {"pace_phase": 1, "tile_map": 1}, {"pace_phase": 2, "tile_map": 4},
-                                   {"pace_phase": 3, "tile_map": 0}, {"pace_phase": 1, "tile_map": 6}, {"hand2": 0}])
+                                   {"pace_phase": 3, "tile_map": 0}, {"pace_phase": 1, "tile_map": 6}, {"hand2": 0}, {"hand2": 2}, {"max_launch_steps": 5}])
 @pytest.mark.parametrize("cfg_name,E,K", [("g1_c1_random", 4096, 70), ("g3_c3_dense_simple_distance", 1500, 20),
                                           ("g1_c1_random", 700, 33)])
 def test_tunables_never_change_results(oracle, ccx, cfg_name, E, K, knobs):
@@ -413,4 +413,41 @@ def test_full_size_c5_greedy_rollout_equals_the_oracle(oracle, ccx, name, eps):
         assert env.counters() == ob.counters.as_dict()
     finally:
         oracle.OracleBatch.set_policy_epsilon(0.0)
+        env.close()
+
+
+def test_long_rollouts_are_cut_into_launches_without_changing_a_bit(ccx, oracle):
+    """The writer waves address rewards / flag bytes / compact rows with 32-bit offsets from the stream's base, so
+    `ccx_rollout` cuts a rollout whose small streams would exceed 4 GiB into several launches on the stream
+    (ccx_api.hip: run_rollout).  Forced here with the `max_launch_steps` tunable: 45 steps in launches of at most 7,
+    tensor actions with a shuffled move order and the in-kernel greedy policy, auto-reset -- every output equals the
+    oracle's single 45-step rollout."""
+    from collectivecrossing_amd.reset import build_reset_pool
+    g = Golden("g1_c1_random")
+    E, K = 37, 45
+    pool = build_reset_pool(g.config, 7, 64)
+    rng = np.random.default_rng(5)
+    acts = rng.integers(0, 5, size=(K, E, g.N), dtype=np.uint8)
+    order = np.stack([np.stack([rng.permutation(g.N) for _ in range(E)]) for _ in range(K)]).astype(np.uint8)
+    ob, env = oracle.OracleBatch(g.params, E), ccx(g.config, E)
+    try:
+        env.set_tunable("max_launch_steps", 7)
+        for b in (ob, env):
+            b.set_reset_pool(pool)
+            b.reset_from_pool()
+        o_obs, o_rew, o_af, o_ef = ob.rollout(acts, order=order, auto_reset=True)
+        res = env.rollout(acts, order=order, auto_reset=True, want_compact=True)
+        np.testing.assert_array_equal(_np(res.obs).view(np.uint32), o_obs.view(np.uint32))
+        np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64))
+        np.testing.assert_array_equal(_np(res.agent_flags), o_af)
+        np.testing.assert_array_equal(_np(res.env_flags), o_ef)
+        np.testing.assert_array_equal(_np(env.expand_observations(res.obs_compact)).view(np.uint32), o_obs.view(np.uint32))
+        o_act, o_obs, o_rew, o_af, o_ef = ob.rollout_greedy(K, auto_reset=True)
+        res, a = env.rollout_greedy(K, auto_reset=True)
+        np.testing.assert_array_equal(_np(a), o_act)
+        np.testing.assert_array_equal(_np(res.obs).view(np.uint32), o_obs.view(np.uint32))
+        np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64))
+        np.testing.assert_array_equal(_np(res.agent_flags), o_af)
+        assert env.counters() == ob.counters.as_dict()
+    finally:
         env.close()

@@ -39,8 +39,10 @@ def _kernels(tmp_path):
             name = re.search(r"\.name:\s+(\S+)", block)
             vgpr = re.search(r"\.vgpr_count:\s+(\d+)", block)
             scratch = re.search(r"\.private_segment_fixed_size:\s+(\d+)", block)
+            sspill = re.search(r"\.sgpr_spill_count:\s+(\d+)", block)
             if name and vgpr:
-                out[name.group(1)] = (int(vgpr.group(1)), int(scratch.group(1)) if scratch else 0)
+                out[name.group(1)] = (int(vgpr.group(1)), int(scratch.group(1)) if scratch else 0,
+                                      int(sspill.group(1)) if sspill else 0)
     return out
 
 
@@ -90,9 +92,29 @@ def test_rollout_kernels_fit_sixteen_wavefronts_per_cu(tmp_path):
     assert len(occ) >= 80
     over = {k: v for k, v in occ.items() if v[0] > 128}
     assert not over, f"instantiations over 128 VGPRs (12 instead of 16 wavefronts per CU): {over}"
-    # no scratch in the plain instantiations (the bench line, RL stepping) nor in the 64-lane policy ones (C5); the
-    # register-bounded policy / move-order instantiations of smaller lane groups may spill a few dwords
-    spills = {k: v for k, v in occ.items() if v[1] > (16 if ("v128" in k and "ILi6E" not in k) else 0)}
+    # no scratch in the plain instantiations (the bench line, RL stepping); the policy / move-order instantiations report a
+    # 20-byte private segment (the register scavenger's emergency slot next to their SGPR spills: the code objects hold no
+    # scratch instruction, `llvm-objdump -d` shows none) -- anything beyond that would be a real VGPR spill
+    spills = {k: v for k, v in occ.items() if v[1] > (20 if "v128" in k else 0)}
     assert not spills, f"scratch spills: {spills}"
     hot = [v for k, v in occ.items() if "ILi3ELb1ELi1ELb1ELb1E" in k and "v128" not in k]     # C2's kernel
     assert hot and hot[0][0] <= 128
+
+
+def test_sgpr_spills_of_the_hot_instantiations(tmp_path):
+    """`.sgpr_spill_count` of the code objects (the round-2 kernels carried 36-103 spilled SGPRs and reloaded
+    up to 67 of them through v_readlane per env-step).  Every kernel argument is now read from the kernel-argument segment
+    where it is used, the small-output streams advance 32-bit lane offsets instead of 64-bit scalar pointers, and the
+    epilogue re-derives its lane predicates: the plain instantiations with outputs (the bench line <3,1,1,1,1>, <5,...>,
+    <6,...>) and all instantiations without outputs spill NOTHING; the policy / move-order and edge-iteration
+    instantiations keep a bounded handful outside their step loops (C5: v128<6,1,1,1,0> 17, <6,1,2,1,0> 27; round 2: 87 / 103)."""
+    ks = {k: v for k, v in _kernels(tmp_path).items() if "rollout_kernel" in k}
+    occ = {k: v for k, v in ks.items() if re.search(r"ILi\dELb[01]ELi[012]ELb1ELb[01]E", k)}
+    plain_out = {k: v[2] for k, v in occ.items() if re.search(r"ILi\dELb[01]ELi[01]ELb1ELb1E", k) and "v128" not in k}
+    assert len(plain_out) >= 28 and not any(plain_out.values()), {k: v for k, v in plain_out.items() if v}
+    for tag in ("ILi3ELb1ELi1ELb1ELb1E", "ILi5ELb1ELi1ELb1ELb1E", "ILi6ELb1ELi1ELb1ELb1E"):
+        assert [v for k, v in plain_out.items() if tag in k] == [0], tag
+    rest = {k: v[2] for k, v in occ.items() if k not in plain_out}
+    assert max(rest.values()) <= 48, {k: v for k, v in rest.items() if v > 48}
+    c5 = {k: v[2] for k, v in occ.items() if re.search(r"v128ILi6ELb1ELi[12]ELb1ELb0E", k)}
+    assert len(c5) == 2 and max(c5.values()) <= 32, c5
