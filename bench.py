@@ -22,8 +22,10 @@ Timing protocol.  Exactly W untimed launches, then K timed launches between barr
 pairs, max over ranks: that is the `cold` block of the line.  The first ~30 launches of a process run
 slower (clock ramp, pace controller start-up), so when W + K < 80 the difference is
 run as further untimed set-up (`config.settle_launches`) and K launches are timed again the same way:
-`value` is that steady-state figure, `cold.value` the one a caller with exactly W warm-ups sees; with
-W >= 80 they are the same measurement.
+`value` is that steady-state figure (`value_protocol` says so in the line), `cold.value` the one a caller with
+exactly W warm-ups sees; with W >= 80 they are the same measurement.  No number depends on state outside the
+process: the pace controller's start value is measured in-process (`config.pace_start_source`: "calibration");
+a pace cache is used only if the caller names one (CCX_PACE_CACHE -> "user_cache").
 
 Prints ONE JSON line on rank 0.  `value` = env-steps/s over ALL ranks with inputs resident in HBM.
 Weak scaling: every rank owns 4096 envs of a global batch of N*4096; envs are independent, the only
@@ -182,7 +184,7 @@ def traffic_from_profiles(workload: str, E: int, N: int, chunk: int):
     """HBM bytes per launch from the PMC passes of an EARLIER rocprofv3 run of this same command
     (profiles/collect*.sh; counters cannot be collected inside a plain bench run).  Replayed from the
     tracked file, never measured here -- hence not `roofline.traffic`."""
-    names = ["r02_c2_traffic.json", "r01_traffic.json"] if workload == "c2" else [f"r02_{workload}_traffic.json"]
+    names = ([f"r03_{workload}_traffic.json", f"r02_{workload}_traffic.json"] + (["r01_traffic.json"] if workload == "c2" else []))
     for name in names:
         f = ROOT / "profiles" / name
         try:
@@ -470,14 +472,17 @@ def run_rank(args) -> int:
     def summarize(elapsed, launch_ms):
         kern_ms = float(np.mean(launch_ms)) if launch_ms else float("nan")
         achieved = launch_bytes / (kern_ms * 1e-3) / 1e9 if launch_ms else float("nan")
+        wall = launch_bytes * args.steps / elapsed / 1e9          # the same bytes over the barrier-to-barrier wall clock
         return {"value": args.steps * chunk * total / elapsed, "ms_per_step": elapsed * 1e3 / args.steps,
                 "kernel_ms_per_launch": kern_ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                "frac_wall": wall / HBM_PEAK_GBS,
                 "kernel_ms_max_over_median": (float(np.max(launch_ms) / np.median(launch_ms)) if launch_ms else None)}
 
     # exactly --warmup untimed launches, then the timed window: what a caller with W warm-ups sees
     run(args.warmup)
     elapsed, mine, launch_ms, counters = timed_window()
     cold = summarize(elapsed, launch_ms)
+    pace_start = env.pace_start()     # (after the first long launch: that is where a calibration happens)
     settle = 0
     if args.warmup + args.steps < SETTLE_LAUNCHES and not os.environ.get("CCX_BENCH_NO_SETTLE"):
         # not in steady state yet: finish the start-up untimed and measure again
@@ -507,6 +512,9 @@ def run_rank(args) -> int:
                                    else "torch.distributed" if world > 1 else None),
             "launcher": os.environ.get("CCX_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else None),
             "per_rank_env_steps_per_sec": per_rank,
+            "value_protocol": ("steady state: the requested --steps launches timed again after config.settle_launches "
+                               "further untimed launches; the figure for EXACTLY --warmup + --steps is `cold`"
+                               if settle else "exactly --warmup untimed launches, then --steps timed ones (= `cold`)"),
             "ms_per_step": steady["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "dtypes": "int32/u8 state and flags, f32 observations (exact integers), f64 rewards (one multiply)",
@@ -516,7 +524,13 @@ def run_rank(args) -> int:
                              "config.settle_launches further untimed launches",
                      "value": cold["value"], "ms_per_step": cold["ms_per_step"],
                      "kernel_ms_per_launch": cold["kernel_ms_per_launch"],
+                     "frac": cold["frac"], "frac_wall": cold["frac_wall"],
+                     "pace_start_source": pace_start["source"],
                      "ratio_to_value": cold["value"] / env_sps},
+            # the same window when nothing outside this process seeded the controller (no pace cache: the default)
+            "cold_unseeded": ({"value": cold["value"], "ratio_to_value": cold["value"] / env_sps,
+                               "pace_start_source": pace_start["source"]}
+                              if pace_start["source"] != "user_cache" else None),
             "config": {"workload": ("C2: 4096 envs x (5 boarding + 3 exiting) per GPU, 12x8 grid, "
                                     "DefaultReward + DefaultObservation, individual_at_destination, "
                                     "max_steps=100, uniform random actions, auto-reset from "
@@ -532,13 +546,15 @@ def run_rank(args) -> int:
                        "ms_per_env_step": elapsed * 1e3 / (args.steps * chunk),
                        "settle_launches": settle,
                        "launch_shape": env.launch_shape(), "step_pace_ns": env.step_pace_ns(),
+                       "pace_start_source": pace_start["source"], "pace_start_ns": pace_start["ns"],
+                       "pace_probe_GBs": pace_start["probe_GBs"],
                        "outputs": "full trajectory" + (" (compact obs [E][N][4] instead of the rows)" if args.compact_obs
                                                        else " (no obs)" if args.no_obs else "")},
             "counters": counters,
             "device": {"name": props.name, "compute_units": props.multi_processor_count,
                        "hbm_GiB": round(props.total_memory / 2**30, 1)},
             "roofline": {"bound": "hbm", "achieved": steady["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": steady["frac"], "frac_cold": cold["frac"],
+                         "frac": steady["frac"], "frac_wall": steady["frac_wall"], "frac_cold": cold["frac"],
                          "traffic": None,
                          "traffic_from_profiles": traffic_from_profiles(args.workload, E, N, chunk),
                          "kernel": "ccx::rollout_kernel", "kernel_ms_per_launch": kern_ms,

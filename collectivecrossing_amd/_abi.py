@@ -127,6 +127,8 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_get_step_pace": (C.c_int, [_H, C.POINTER(C.c_float)]),
     "ccx_get_pace_state": (C.c_int, [_H, C.POINTER(C.c_float)]),
     "ccx_set_step_pace_start": (C.c_int, [_H, C.c_float]),
+    "ccx_set_pace_calibration": (C.c_int, [_H, C.c_int32]),
+    "ccx_get_pace_start": (C.c_int, [_H, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "ccx_set_tunable": (C.c_int, [_H, C.c_char_p, C.c_int32]),
     "ccx_get_residency": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccx_get_writer_shape": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -371,14 +371,19 @@ class BatchedCollectiveCrossing:
         """Start value of the adaptive pace controller (``ccx_set_step_pace_start``), 0 = library default."""
         check(self._lib.ccx_set_step_pace_start(self._h, float(ns_per_env_step)))
 
-    # -- pace memory: the adaptive controller needs ~30 launches to find the drain rate of a box; a handle
-    # of a shape seen before starts from what was learned (user cache first, then the values shipped in
-    # pace_defaults.json, measured on MI355X).  Never affects results.
-    _PACE_DEFAULTS = Path(__file__).resolve().parent / "pace_defaults.json"
+    # -- where the pace controller starts.  By default the library MEASURES it in-process (ccx_set_pace_calibration: a
+    # ~2.5 ms write probe of the caller's own trajectory buffer at the first long rollout).  A pace memory across processes
+    # is opt-in: only when CCX_PACE_CACHE names a file does a handle start from the pace an earlier handle of the same
+    # shape settled at, and only then is the file updated on close() (never from a multi-rank job: N ranks would
+    # read-modify-write one file).  Nothing is ever read from or written to $HOME implicitly.  Never affects results.
+    PACE_START_SOURCES = {0: "unpaced", 1: "assumed", 2: "caller", 3: "calibration", 4: "fixed"}
 
     @staticmethod
-    def _pace_cache_path() -> Path:
-        return Path(os.environ.get("CCX_PACE_CACHE") or Path.home() / ".cache" / "collectivecrossing_amd" / "pace.json")
+    def _pace_cache_path() -> Path | None:
+        p = os.environ.get("CCX_PACE_CACHE")
+        if not p or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            return None
+        return Path(p)
 
     def _pace_key(self) -> str:
         s = self.launch_shape()
@@ -389,25 +394,26 @@ class BatchedCollectiveCrossing:
                 f"|tpb{s['waves_per_block']}|w{s['writers_per_tile']}")
 
     def _apply_pace_memory(self) -> None:
-        if os.environ.get("CCX_PACE_MEMORY", "1") in ("", "0"):
+        """(Re)applied whenever the launch shape changes: the key names the shape."""
+        self._pace_from_cache = False
+        path = self._pace_cache_path()
+        if path is None:
             return
-        key = self._pace_key()
-        for path in (self._pace_cache_path(), self._PACE_DEFAULTS):
-            try:
-                ns = float(json.loads(path.read_text())[key]["pace_ns"])
-            except Exception:
-                continue
-            if ns > 0:
-                self.set_step_pace_start(ns * 1.01)      # start a notch on the safe side of the remembered pace
-                return
+        try:
+            ns = float(json.loads(path.read_text())[self._pace_key()]["pace_ns"])
+        except Exception:
+            return
+        if ns > 0:
+            self.set_step_pace_start(ns * 1.01)      # start a notch on the safe side of the remembered pace
+            self._pace_from_cache = True
 
     def _remember_pace(self) -> None:
-        if self._rollouts_with_obs < 40 or os.environ.get("CCX_PACE_MEMORY", "1") in ("", "0"):
+        path = self._pace_cache_path()
+        if path is None or self._rollouts_with_obs < 40:
             return
         ns = self.step_pace_ns()
         if not ns > 0:
             return
-        path = self._pace_cache_path()
         try:
             data = json.loads(path.read_text())
         except Exception:
@@ -417,6 +423,21 @@ class BatchedCollectiveCrossing:
         tmp = path.with_suffix(f".tmp{os.getpid()}")
         tmp.write_text(json.dumps(data, indent=1, sort_keys=True))
         tmp.replace(path)
+
+    def pace_start(self) -> dict:
+        """Where the adaptive pace controller started (``ccx_get_pace_start``): ``ns`` per env-step, ``source`` in
+        {"unpaced", "assumed", "caller", "calibration", "fixed", "user_cache"} ("user_cache" = a caller's value that came
+        from the CCX_PACE_CACHE file), ``probe_GBs`` = the write rate the calibration probe measured (0 = it has not run)."""
+        ns, src, gbs = C.c_float(), C.c_int32(), C.c_float()
+        check(self._lib.ccx_get_pace_start(self._h, C.byref(ns), C.byref(src), C.byref(gbs)))
+        source = self.PACE_START_SOURCES.get(int(src.value), str(src.value))
+        if source == "caller" and getattr(self, "_pace_from_cache", False):
+            source = "user_cache"
+        return {"ns": float(ns.value), "source": source, "probe_GBs": float(gbs.value)}
+
+    def set_pace_calibration(self, enabled: bool = True) -> None:
+        """In-process start-up calibration of the pace controller (``ccx_set_pace_calibration``; default on)."""
+        check(self._lib.ccx_set_pace_calibration(self._h, int(bool(enabled))))
 
     def set_timing(self, enabled: bool = True) -> None:
         """Record HIP events around every launch so that ``last_launch_ms`` works (off by default)."""
@@ -429,9 +450,17 @@ class BatchedCollectiveCrossing:
 
     def set_launch_shape(self, lanes_per_wave: int = 0, waves_per_block: int = 0) -> None:
         check(self._lib.ccx_set_launch_shape(self._h, lanes_per_wave, waves_per_block))
+        self._shape_changed()
 
     def set_writers(self, writers_per_tile: int = 0) -> None:
         check(self._lib.ccx_set_writers(self._h, writers_per_tile))
+        self._shape_changed()
+
+    def _shape_changed(self) -> None:
+        """A remembered start value belongs to ONE launch shape: drop it, look the new shape up."""
+        if getattr(self, "_pace_from_cache", False):
+            self.set_step_pace_start(0.0)
+        self._apply_pace_memory()
 
     def set_store_throttle(self, max_stores_in_flight: int = 0) -> None:
         check(self._lib.ccx_set_store_throttle(self._h, max_stores_in_flight))

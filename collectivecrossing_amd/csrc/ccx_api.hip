@@ -276,10 +276,12 @@ int choose_shape(ccx_handle* h) {
     CCX_HIP(hipMemcpy(h->obs_table, h->obs_table_host.data(), h->obs_table_host.size() * sizeof(uint16_t),
                       hipMemcpyHostToDevice));
     k.obs_table = h->obs_table;
-    k.pace_min_fp = to_fp(s.step_bytes / 7800.0);
+    k.pace_min_fp = to_fp(s.step_bytes / 8000.0);    // (the spec peak; round 2 stopped at 7.8 TB/s, which multi-tile-per-CU shapes now reach)
     k.pace_max_fp = to_fp(s.step_bytes / 1100.0);
     h->pace_init_fp = h->step_pace_ns > 0 ? to_fp((double)h->step_pace_ns)
                       : h->pace_start_ns > 0.0f ? to_fp((double)h->pace_start_ns) : to_fp(s.step_bytes / 6800.0);
+    h->pace_start_source = h->step_pace_ns > 0 ? CCX_PACE_START_FIXED
+                           : h->pace_start_ns > 0.0f ? CCX_PACE_START_CALLER : CCX_PACE_START_ASSUMED;
     h->pace_dirty = true;
     k.r_dest = p.boarding_destination_reward; k.r_door = p.tram_door_reward;
     k.r_area = p.tram_area_reward; k.r_f = p.distance_penalty_factor;
@@ -351,6 +353,48 @@ int end_timed(ccx_handle* h) {
 int* g_lag_buf = nullptr;
 #endif
 
+// Start-up calibration of the pace controller.  The adaptive controller needs a start value within
+// a few per cent of the rate at which THIS box drains THIS process's write stream; round 2 shipped four learned values
+// for the four bench shapes and started every other shape from an assumed 6.8 TB/s.  Now the first paced launch of a
+// handle / launch shape measures it: a pure write stream (the writer waves' own store instruction) into the caller's
+// trajectory buffer -- the memory the rollout is about to overwrite anyway -- for ~2.5 ms (which also takes the memory
+// side through its start-up transient), best pass wins.  The paced rollouts of all shapes settle at 1.05-1.15 x that
+// rate (round 3: C2 7.3-7.6 TB/s vs fills of 6.4-7.1 in the same process), so the controller starts 5 % above the
+// measured rate and keeps descending at its fast rate until a launch comes in late.  Synchronises the stream once; skipped inside a stream capture, with a caller's start value
+// (ccx_set_step_pace_start), with a fixed pace, or with ccx_set_pace_calibration(h, 0) / CCX_PACE_CALIBRATION=0.
+int calibrate_pace(ccx_handle* h, float* obs, size_t obs_bytes) {
+    const size_t bytes = std::min<size_t>(obs_bytes & ~(size_t)15, (size_t)3 << 30);
+    if (bytes < ((size_t)16 << 20)) return CCX_OK;            // too small a buffer to say anything about a stream
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    CCX_HIP(hipEventCreate(&e0));
+    CCX_HIP(hipEventCreate(&e1));
+    double best_gbs = 0.0, spent_ms = 0.0;
+    int rc = CCX_OK;
+    for (int pass = 0; pass < 24 && spent_ms < 2.5 && rc == CCX_OK; ++pass) {
+        float ms = 0.0f;
+        hipError_t e = hipEventRecord(e0, h->stream);
+        if (e == hipSuccess) e = ccx::launch_write_probe(h->stream, obs, bytes, h->num_cus * 8);
+        if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) rc = fail(CCX_EHIP, "pace calibration probe failed: %s", hipGetErrorString(e));
+        else if (ms > 0.0f) {
+            spent_ms += ms;
+            best_gbs = std::max(best_gbs, (double)bytes / ((double)ms * 1.0e6));
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    if (best_gbs > 1000.0 && best_gbs < 12000.0) {            // (a sane measurement; else keep the assumption)
+        auto to_fp = [](double ns) { double v = ns / 10.0 * 256.0; return (uint32_t)(v < 1.0 ? 1.0 : (v > 4.0e9 ? 4.0e9 : v)); };
+        h->pace_probe_gbs = (float)best_gbs;
+        h->pace_init_fp = std::min(std::max(to_fp(h->shape.step_bytes / (best_gbs * 1.05)), h->kp.pace_min_fp), h->kp.pace_max_fp);
+        h->pace_start_source = CCX_PACE_START_CALIBRATED;
+    }
+    return CCX_OK;
+}
+
 int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* order, int auto_reset,
                 const ccx::KOut& out, int policy = 0, uint8_t* actions_out = nullptr) {
     // The writer waves address the small output streams (rewards, flag bytes, compact rows, chosen actions) with 32-bit
@@ -386,17 +430,45 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     if (out.obs_compact && (reinterpret_cast<uintptr_t>(out.obs_compact) & 15u))
         return fail(CCX_EINVAL, "obs_compact buffer must be 16-byte aligned");
     CCX_HIP(hipSetDevice(h->device));
+    const bool writes_obs = out.obs != nullptr;
+    bool capturing = false;
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess) (void)hipGetLastError();
+        else capturing = cap != hipStreamCaptureStatusNone;
+    }
     if (h->pace_dirty) {   // (re)start the pace controller: new handle, new launch shape or new setting
-        CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state), 0, 8, h->stream));   // floor, cliff memory = 0
-        CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state + h->pace_slot),
-                                  (int)h->pace_init_fp, 1, h->stream));
-        // A start value from the caller (ccx_set_step_pace_start: the pace a previous handle of this shape settled at)
-        // is also the first FLOOR: without one the controller descends 1.6 % per launch until its first collapse,
-        // which a process that already knows its pace can skip -- and the first milliseconds of a process collapse
-        // at paces that are fine later.  The floor decays as always (0.1 % per launch at first, then faster).
-        if (h->pace_start_ns > 0.0f && h->step_pace_ns == 0)
-            CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state + 2), (int)h->pace_init_fp, 1, h->stream));
-        h->pace_dirty = false;
+        // Never inside a stream capture: the memsets would become graph nodes and every replay would re-zero the
+        // controller's state, and the calibration must synchronise.  A launch that needs the (re)start is
+        // refused while capturing; run one eager launch of the shape first.
+        if (capturing && ccx::launch_is_paced(h->kp.pace_state != nullptr, writes_obs, K))
+            return fail(CCX_EINVAL, "the pace controller of this handle must be (re)started (new handle, launch shape or "
+                        "setting): run one eager rollout of this shape before capturing it into a graph");
+        const bool paced_launch = ccx::launch_is_paced(h->kp.pace_state != nullptr, writes_obs, K);
+        if (!h->kp.pace_state) {
+            h->pace_dirty = false;              // rollouts of this shape are not paced at all
+        } else if (!capturing && paced_launch) {   // (launches that are not paced never look at the controller: nothing to do yet)
+            const bool adaptive_launch =
+                ccx::launch_is_adaptive(h->kp.pace_state != nullptr, h->kp.pace_adapt != 0u, writes_obs, K);
+            const bool wants_calibration = h->kp.pace_adapt != 0u && h->pace_calibrate && h->pace_start_ns <= 0.0f;
+            if (adaptive_launch && wants_calibration) {
+                const size_t obs_bytes = (size_t)K * (size_t)h->E * h->N * (size_t)(6 + 4 * h->N) * sizeof(float);
+                const int rc = calibrate_pace(h, out.obs, obs_bytes);
+                if (rc) return rc;
+            }
+            CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state), 0, 8, h->stream));   // floor, cliff memory = 0
+            CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state + h->pace_slot),
+                                      (int)h->pace_init_fp, 1, h->stream));
+            // A start value from the caller (ccx_set_step_pace_start: the pace a previous handle of this shape settled at)
+            // is also the controller's first FLOOR: a process that already knows its pace skips the descent into a first
+            // collapse; the floor decays as always.  A CALIBRATED start gets no floor: the probe is a lower bound of what
+            // the paced stream reaches (measured: the paced rollouts settle 5-15 % above a plain fill of the same buffer),
+            // so the controller descends from it at its fast rate (1.6 % per launch) until the memory side says stop.
+            if (h->step_pace_ns == 0 && h->pace_start_ns > 0.0f)
+                CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state + 2), (int)h->pace_init_fp, 1, h->stream));
+            // (a paced launch too short to calibrate on keeps the assumption; the first long one calibrates and restarts)
+            h->pace_dirty = wants_calibration && !adaptive_launch;
+        }
     }
     h->kp.pace_slot = h->pace_slot;
     if (h->check_inputs && actions) {
@@ -410,7 +482,6 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     ccx::KParams kp = h->kp;
     // launches the kernel will not pace hand steps to the writer waves through sequence words (ccx_kernels.h: one
     // definition of the launch modes for the host and the kernel)
-    const bool writes_obs = out.obs != nullptr;
     kp.hand_flags = ccx::launch_uses_flags(kp.pace_state != nullptr, writes_obs, K, h->tun_hand2) ? 1u : 0u;
 #ifdef CCX_LAG_TRACE
     {
@@ -424,13 +495,7 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     }
 #endif
     const bool adaptive = ccx::launch_is_adaptive(kp.pace_state != nullptr, kp.pace_adapt != 0u, writes_obs, K);
-    bool capturing = false;
-    if (adaptive) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess) (void)hipGetLastError();
-        else capturing = cap != hipStreamCaptureStatusNone;
-        if (capturing) kp.pace_adapt = 0u;
-    }
+    if (adaptive && capturing) kp.pace_adapt = 0u;
     int rc = begin_timed(h);
     if (rc) return rc;
     hipError_t e = ccx::launch_rollout(h->shape, h->stream, kp, h->st, h->cell_info, actions,
@@ -535,6 +600,7 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
         ccx_destroy(h);
         return code;
     }
+    if (const char* ev = getenv("CCX_PACE_CALIBRATION")) h->pace_calibrate = !(ev[0] == '0' && ev[1] == 0);
     rc = choose_shape(h);
     if (rc) {
         ccx_destroy(h);
@@ -902,6 +968,20 @@ int ccx_set_step_pace_start(ccx_handle* h, float ns_per_env_step) {
         return fail(CCX_EINVAL, "ns_per_env_step must be 0 (library default) or a positive number of nanoseconds");
     h->pace_start_ns = ns_per_env_step;
     return choose_shape(h);
+}
+
+int ccx_set_pace_calibration(ccx_handle* h, int32_t enabled) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    h->pace_calibrate = enabled != 0;
+    return choose_shape(h);
+}
+
+int ccx_get_pace_start(ccx_handle* h, float* ns_per_env_step, int32_t* source, float* probe_gbs) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if (ns_per_env_step) *ns_per_env_step = h->kp.pace_state ? (float)((double)h->pace_init_fp / 256.0 * 10.0) : 0.0f;
+    if (source) *source = h->kp.pace_state ? h->pace_start_source : CCX_PACE_START_UNPACED;
+    if (probe_gbs) *probe_gbs = h->pace_probe_gbs;
+    return CCX_OK;
 }
 
 int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {

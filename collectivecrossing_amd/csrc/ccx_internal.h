@@ -50,6 +50,9 @@ struct ccx_handle {
     uint32_t pace_slot = 0;                                    // slot of pace_state the next launch reads
     int num_cus = 256;
     float pace_start_ns = 0.0f;                                // > 0: the adaptive controller starts here (ccx_set_step_pace_start)
+    bool pace_calibrate = true;                                // measure the start value in-process (ccx_set_pace_calibration)
+    int pace_start_source = 0;                                 // CCX_PACE_START_*: where the controller's start value came from
+    float pace_probe_gbs = 0.0f;                               // write rate the calibration probe measured (GB/s), 0 = not run
     int tun_pace_phase = -1, tun_tile_map = -1;                 // -1 = the library's choice for the launch shape
     int tun_writer_roles = -1;                                  // -1 = by batch size, 0 = writers share everything, 1 = writer 0 small outputs only
     int tun_hand2 = 1;                                          // sim -> writer hand-off: 0 barrier per step, 1 sequence words in unpaced launches, 2 always

@@ -193,6 +193,8 @@ hipError_t launch_expand(const LaunchShape& ls, hipStream_t stream, const KParam
                          long long rows, float* obs);
 hipError_t launch_reset_from_pool(hipStream_t stream, const KParams& p, const KState& st,
                                   const uint8_t* env_mask, const uint8_t* pool);
+// streams `bytes` (a multiple of 16) of filler into `dst` with the rollout's own store instruction: the pace calibration probe
+hipError_t launch_write_probe(hipStream_t stream, void* dst, size_t bytes, int blocks);
 
 // CCX_CHECK_INPUTS: counts action bytes outside {0..4, 255} into bad[0] and move-order rows that are not a
 // permutation of 0..N-1 into bad[1] (collectivecrossing.py:685-711), one thread per (step, env) row

@@ -638,6 +638,28 @@ hipError_t launch_expand(const LaunchShape& ls, hipStream_t stream, const KParam
     return launch_observe_any(ls, stream, q, KState{}, obs, reinterpret_cast<const float4*>(compact), (unsigned)blocks);
 }
 
+// Pace calibration probe (ccx_api.hip: calibrate_pace): a plain fill of the caller's own trajectory buffer -- one
+// workgroup per 16 KiB, four 16-byte stores per lane, cached stores like a library fill (measured: streaming `nt` stores
+// issued flat out, without the rollout's pacing, drain 25 % slower than the paced rollout does and are no yardstick for
+// it; a plain fill lands within a few per cent of it on every box seen).  What it writes is overwritten by the rollout
+// that follows.
+__global__ void __launch_bounds__(256) write_probe_kernel(v4f* __restrict__ dst, const size_t n16) {
+    const v4f filler = {0.0f, 0.0f, 0.0f, 0.0f};
+    const size_t base = (size_t)blockIdx.x * 1024u + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t q = base + (size_t)k * 256u;
+        if (q < n16) dst[q] = filler;
+    }
+}
+
+hipError_t launch_write_probe(hipStream_t stream, void* dst, size_t bytes, int) {
+    if (bytes < 16) return hipSuccess;
+    const size_t n16 = bytes / 16, blocks = (n16 + 1023) / 1024;
+    hipLaunchKernelGGL(write_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<v4f*>(dst), n16);
+    return hipGetLastError();
+}
+
 hipError_t launch_reset_from_pool(hipStream_t stream, const KParams& p, const KState& st,
                                   const uint8_t* env_mask, const uint8_t* pool) {
     const size_t total = (size_t)p.E * p.N;

@@ -347,7 +347,8 @@ int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight);
 /* Step pacing of rollouts that write observations: every env tile starts env-step s no earlier than
  * t0 + s * pace on the GPU's 100 MHz clock, which turns the output into a smooth stream at (just under)
  * the HBM drain rate instead of bursts that oversubscribe the write queues.
- *   0  = adaptive (default): starts from an assumed 6.8 TB/s and is retuned by the kernel after every
+ *   0  = adaptive (default): starts from the write rate measured in-process at the first long rollout
+ *        (ccx_set_pace_calibration; an assumed 6.8 TB/s without it) and is retuned by the kernel after every
  *        launch of >= 64 steps (late => slower, on time => 0.4 % faster, a collapse of the drain rate =>
  *        +3 % and a decaying floor); batches too small to fill the drain rate are not paced at all
  *   -1 = off;   > 0 = fixed pace in nanoseconds per env-step.
@@ -364,6 +365,23 @@ int ccx_get_pace_state(ccx_handle* h, float* out6);
  * floor), so that the start of a process is not spent probing below a pace that is already known.  Restarts the
  * controller. */
 int ccx_set_step_pace_start(ccx_handle* h, float ns_per_env_step);
+/* Start-up calibration (default on; CCX_PACE_CALIBRATION=0 in the environment turns it off for new handles).  The first
+ * adaptive paced rollout of a handle / launch shape -- one that writes observations for >= 64 steps -- first streams
+ * filler into the caller's own observation buffer (which that rollout overwrites anyway) for ~2.5 ms with the writer
+ * wavefronts' store type, takes the best pass as a lower bound of the drain rate of this box and starts the controller
+ * 5 % above it (it descends further by itself until a launch comes in late).  One stream synchronisation; never inside a stream capture (a rollout that would have to restart
+ * the controller while capturing fails with CCX_EINVAL: run one eager rollout of the shape first).  Without it -- or
+ * before the first such rollout -- the start value is an assumed 6.8 TB/s. */
+int ccx_set_pace_calibration(ccx_handle* h, int32_t enabled);
+/* where the pace controller started: the value (ns per env-step; 0 if rollouts of this shape are not paced), its
+ * source (CCX_PACE_START_*) and the write rate the calibration probe measured (GB/s, 0 = it did not run).  Any pointer
+ * may be NULL. */
+#define CCX_PACE_START_UNPACED    0  /* rollouts of this shape are not paced (too small to be memory-bound, or pacing off) */
+#define CCX_PACE_START_ASSUMED    1  /* the library's assumption (6.8 TB/s): no calibration has run (yet)                  */
+#define CCX_PACE_START_CALLER     2  /* ccx_set_step_pace_start                                                           */
+#define CCX_PACE_START_CALIBRATED 3  /* measured in-process at the first adaptive rollout                                 */
+#define CCX_PACE_START_FIXED      4  /* ccx_set_step_pace(h, ns > 0): no controller                                       */
+int ccx_get_pace_start(ccx_handle* h, float* ns_per_env_step, int32_t* source, float* probe_gbs);
 /* Performance experiments without an ABI change; results never depend on a tunable.  -1 = the library's
  * choice for the launch shape (pace_phase, tile_map).
  *   "pace_phase"   0 = every tile starts env-step s at t0 + s * pace, 1 = tiles are phased over the step

@@ -19,6 +19,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--workload $W --policy $P --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $ROOT/bench.py $ARGS > $OUT/${R}_${W}_bench.json 2> $OUT/kt.err || { tail -5 $OUT/kt.err; exit 1; }
+export CCX_BENCH_NO_SETTLE=1    # the PMC passes time nothing: no settle launches inside the counter window
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3 $ROOT/bench.py $ARGS --steps 2 --warmup 6 > $OUT/bench_write.json 2> $OUT/write.err || { tail -5 $OUT/write.err; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python3 $ROOT/bench.py $ARGS --steps 2 --warmup 6 > $OUT/bench_fetch.json 2> $OUT/fetch.err || { tail -5 $OUT/fetch.err; exit 1; }
 python3 - <<PY

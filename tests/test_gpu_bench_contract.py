@@ -52,9 +52,30 @@ def test_bench_line_has_the_contract_fields_and_adds_up():
     cold = d["cold"]
     assert c["settle_launches"] == 80 - 2 - 3 and cold["value"] > 0 and 0.2 < r["frac_cold"] < 1.0
     assert cold["ratio_to_value"] == pytest.approx(cold["value"] / d["value"], rel=1e-9)
+    # measurement hygiene: nothing outside the process seeds the pace controller -- its start value is
+    # measured in-process -- the line says so, carries the wall-clock fraction next to the HIP-event one and names what
+    # `value` is
+    assert c["pace_start_source"] == "calibration" and c["pace_start_ns"] > 0 and 3000 < c["pace_probe_GBs"] < 9000
+    assert cold["pace_start_source"] == "calibration" and d["cold_unseeded"]["value"] == cold["value"]
+    assert "steady state" in d["value_protocol"]
+    assert r["frac_wall"] == pytest.approx(r["bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9 / 8000.0, rel=1e-9)
+    assert r["frac_wall"] <= r["frac"] * 1.001 and cold["frac_wall"] <= cold["frac"] * 1.001
     assert d["rccl_ranks"] == 0 and d["collective_backend"] is None and d["per_rank_env_steps_per_sec"][0] >= d["value"] * 0.999
     sec = d["secondary"]
     assert 0.1 < sec["no_obs"]["us_per_env_step"] < 5 and 1 < sec["step_k1"]["us_per_step"] < 100
+
+
+def test_bench_with_a_pace_cache_says_so(tmp_path):
+    """Opt-in pace memory (CCX_PACE_CACHE names the file; nothing is ever read from or written to $HOME): the first run
+    leaves the learned pace there, the second starts from it and labels its numbers accordingly."""
+    cache = tmp_path / "pace.json"
+    d1 = _run("--steps", "20", "--warmup", "25", "--no-cpu-baseline", "--no-secondary", env={"CCX_PACE_CACHE": str(cache)})
+    assert d1["config"]["pace_start_source"] == "calibration" and cache.exists()
+    key, entry = next(iter(json.loads(cache.read_text()).items()))
+    assert "E4096" in key and entry["pace_ns"] > 0
+    d2 = _run("--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-secondary", env={"CCX_PACE_CACHE": str(cache)})
+    assert d2["config"]["pace_start_source"] == "user_cache" and d2["cold_unseeded"] is None
+    assert d2["config"]["pace_start_ns"] == pytest.approx(entry["pace_ns"] * 1.01, rel=1e-3)
 
 
 def test_bench_cpu_baseline_leg():

@@ -309,11 +309,11 @@ def test_steady_state_launches_have_no_outliers(ccx):
 
 @pytest.mark.parametrize("E", [1024, 2048, 3072])
 def test_small_batches_use_full_tiles_with_two_writers_and_equal_the_oracle(oracle, ccx, E):
-    """Below the memory-bound regime the default shape is full 64-lane tiles with two or three writer waves each,
+    """Below the memory-bound regime the default shape is full 64-lane tiles with two to four writer waves each,
     split by role: same results, of course."""
     g = Golden("g8_rollout_c1")
     c, shape, _, _ = _against_oracle(oracle, ccx, g, E=E, K=70, seed=17 + E)
-    assert (shape["lanes_per_wave"], shape["writers_per_tile"], shape["waves_per_block"]) == (64, 3 if E <= 2048 else 2, 1)
+    assert (shape["lanes_per_wave"], shape["writers_per_tile"], shape["waves_per_block"]) == (64, 4 if E <= 2048 else 2, 1)
     assert c["episodes"] > 0
 
 
@@ -449,5 +449,141 @@ def test_long_rollouts_are_cut_into_launches_without_changing_a_bit(ccx, oracle)
         np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64))
         np.testing.assert_array_equal(_np(res.agent_flags), o_af)
         assert env.counters() == ob.counters.as_dict()
+    finally:
+        env.close()
+
+
+# ---- round 3: start-up calibration of the pace controller, capture guard, launch-mode boundaries -------------------
+def _shape_config(name):
+    from bench import workload_config
+    return workload_config(name)[0]
+
+
+@pytest.mark.parametrize("workload,E,K", [("c2", 6001, 128), ("c3", 3000, 64), ("c5_50", 1000, 64)])
+def test_a_new_shape_starts_within_five_percent_of_its_steady_state(ccx, workload, E, K):
+    """the first paced launch of a shape nobody has seen measures its start value in-process (a
+    ~2.5 ms write probe of the rollout's own observation buffer, ccx_api.hip: calibrate_pace).  Three shapes that never
+    had a shipped or cached pace: launches 5-25 of a fresh handle run within 5 % of launches 80-120."""
+    import torch
+    cfg = _shape_config(workload)
+    env = ccx(cfg, E)
+    try:
+        env.set_timing(True)
+        env.make_reset_pool(0, 512)
+        env.reset_from_pool()
+        assert env.pace_start()["source"] == "assumed" and env.pace_state()["paced"] == 1.0
+        acts = torch.randint(0, 5, (K, E, env.num_agents), dtype=torch.uint8, device=env.device)
+        traj = env.alloc_rollout(K)
+        ms = []
+        for n in range(121):
+            env.rollout(acts, auto_reset=True, out=traj)
+            ms.append(env.last_launch_ms())
+        start = env.pace_start()
+        assert start["source"] == "calibration" and 3000 < start["probe_GBs"] < 9000 and start["ns"] > 0
+        early, late = float(np.mean(ms[5:26])), float(np.mean(ms[80:121]))
+        assert early <= late * 1.05, (workload, early, late, start, ms[:30])
+        assert abs(env.step_pace_ns() / start["ns"] - 1.0) < 0.2, (env.step_pace_ns(), start)   # the probe was in the right place
+    finally:
+        env.close()
+
+
+def test_calibration_can_be_switched_off_and_a_callers_start_value_wins(ccx):
+    import torch
+
+    from bench import c2_config
+    E, K = 4096, 64
+    acts = None
+    for mode in ("off", "caller"):
+        env = ccx(c2_config(), E)
+        try:
+            if mode == "off":
+                env.set_pace_calibration(False)
+            else:
+                env.set_step_pace_start(777.0)
+            env.make_reset_pool(0, 256)
+            env.reset_from_pool()
+            acts = torch.randint(0, 5, (K, E, env.num_agents), dtype=torch.uint8, device=env.device)
+            env.rollout(acts, auto_reset=True)
+            st = env.pace_start()
+            assert st["probe_GBs"] == 0.0
+            assert st["source"] == ("assumed" if mode == "off" else "caller")
+            if mode == "caller":
+                assert abs(st["ns"] - 777.0) < 0.1
+        finally:
+            env.close()
+
+
+def test_capturing_a_paced_rollout_before_its_controller_started_is_refused(ccx):
+    """the (re)start of the pace controller (memsets, calibration) must never become part of a graph -- every
+    replay would re-zero the controller.  A paced rollout captured right after a setting changed fails loudly; one eager
+    launch later the same capture works and replays leave the controller alone."""
+    import torch
+
+    from bench import c2_config
+    from collectivecrossing_amd._lib import CcxError
+    E, K = 4096, 64
+    env = ccx(c2_config(), E)
+    env.make_reset_pool(0, 256)
+    env.reset_from_pool()
+    acts = torch.randint(0, 5, (K, E, env.num_agents), dtype=torch.uint8, device=env.device)
+    traj = env.alloc_rollout(K)
+    side = torch.cuda.Stream(device=env.device)
+    env.use_stream(side)
+    with torch.cuda.stream(side):
+        env.rollout(acts, auto_reset=True, out=traj)
+        env.set_tunable("pace_phase", 1)                      # restarts the controller
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with pytest.raises(CcxError, match="eager rollout"):
+            with torch.cuda.graph(graph, stream=side):
+                env.rollout(acts, auto_reset=True, out=traj)
+        side.synchronize()
+        env.rollout(acts, auto_reset=True, out=traj)          # eager: calibrates / restarts
+        side.synchronize()
+        before = env.pace_state()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            env.rollout(acts, auto_reset=True, out=traj)
+        for _ in range(3):
+            graph.replay()
+        side.synchronize()
+    after = env.pace_state()
+    assert after["next_pace_ns"] == before["next_pace_ns"] and after["floor_ns"] == before["floor_ns"]
+    env.close()
+
+
+@pytest.mark.parametrize("K", [1, 15, 16, 63, 64, 65])
+@pytest.mark.parametrize("pace", [0, -1, 760])
+@pytest.mark.parametrize("obs", [True, False])
+def test_launch_mode_boundaries_against_the_oracle(oracle, ccx, K, pace, obs):
+    """VERDICT r2 item 7.  Whether a launch is paced (pace handle, observations, K >= 16), whether the controller adapts
+    (K >= 64) and whether the sim wave hands steps over through sequence words or a barrier are decided by ONE set of
+    helpers (ccx_kernels.h: launch_is_paced / launch_is_adaptive / launch_uses_flags) shared by run_rollout and the
+    kernel.  Swept here across the boundaries, at a batch size that is paced at all: two launches each (the second one
+    starts from the controller state the first one left), every output equal to the oracle."""
+    from collectivecrossing_amd.reset import build_reset_pool
+    g = Golden("g1_c1_random")
+    E = 4096
+    pool = build_reset_pool(g.config, 3, 64)
+    rng = np.random.default_rng(K * 7 + pace)
+    ob, env = oracle.OracleBatch(g.params, E), ccx(g.config, E)
+    try:
+        env.set_step_pace(pace)
+        for b in (ob, env):
+            b.set_reset_pool(pool)
+            b.reset_from_pool()
+        for launch in range(2):
+            acts = rng.integers(0, 5, size=(K, E, g.N), dtype=np.uint8)
+            o_obs, o_rew, o_af, o_ef = ob.rollout(acts, auto_reset=True)
+            res = env.rollout(acts, auto_reset=True, want_obs=obs)
+            np.testing.assert_array_equal(_np(res.agent_flags), o_af)
+            np.testing.assert_array_equal(_np(res.env_flags), o_ef)
+            np.testing.assert_array_equal(_np(res.reward).view(np.uint64), o_rew.view(np.uint64))
+            if obs:
+                np.testing.assert_array_equal(_np(res.obs).view(np.uint32), o_obs.view(np.uint32))
+            del res, o_obs
+        assert env.counters() == ob.counters.as_dict()
+        paced = env.pace_state()["paced"] == 1.0
+        assert paced == (pace != -1)
     finally:
         env.close()
