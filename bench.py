@@ -331,6 +331,9 @@ def parse_args(argv=None):
     ap.add_argument("--direct-rccl", action="store_true",
                     help="reduce the counters with ccx_rccl_allreduce_counters (RCCL through the C-ABI) instead of "
                          "torch.distributed")
+    ap.add_argument("--buffers", type=int, default=1,
+                    help="diagnostic: cycle the rollouts through this many trajectory buffers (the bench line rewrites ONE; "
+                         "DESIGN.md 3.6: launches that cycle through > 3 GB of output memory sustain less)")
     ap.add_argument("--tunable", action="append", default=[], metavar="NAME=VALUE",
                     help="diagnostic: ccx_set_tunable(NAME, VALUE) on the handle (repeatable)")
     ap.add_argument("--rehearse", action="store_true", help="N>1 plumbing only, no env stepping (CPU-runnable)")
@@ -425,8 +428,9 @@ def run_rank(args) -> int:
     actions = torch.randint(0, 5, (n_buf * chunk, E, N), dtype=torch.uint8, device=dev, generator=gen)
     if args.compact_obs:
         args.no_obs = True
-    traj = env.alloc_rollout(chunk, want_obs=not args.no_obs, want_compact=args.compact_obs)
-    view = traj if not args.only_obs else type(traj)(traj.obs, None, None, None, traj.obs_compact)
+    trajs = [env.alloc_rollout(chunk, want_obs=not args.no_obs, want_compact=args.compact_obs) for _ in range(max(1, args.buffers))]
+    traj = trajs[0]
+    views = [t if not args.only_obs else type(t)(t.obs, None, None, None, t.obs_compact) for t in trajs]
     launched = 0
 
     def run(nlaunches, events=None):
@@ -435,6 +439,7 @@ def run_rank(args) -> int:
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
+            view = views[launched % len(views)]
             if args.policy == "greedy":
                 env.rollout_greedy(chunk, auto_reset=True, out=view, want_actions=False)
             elif args.policy == "device-random":
@@ -542,6 +547,7 @@ def run_rank(args) -> int:
                        "trajectory_buffer": ("every launch rewrites ONE set of [steps, envs, agents] output buffers (a fixed RL rollout "
                                              "buffer, %.2f GB here); launches that cycle through > 3 GB of output memory sustain "
                                              "0.86-0.88 of the peak instead of 0.90 (DESIGN.md 3.6)") % (chunk * E * N * rollout_bytes_per_agent_step(N) / 1e9),
+                       "trajectory_buffers": len(views),
                        "env_steps_per_step": chunk, "steps_per_launch": chunk,
                        "ms_per_env_step": elapsed * 1e3 / (args.steps * chunk),
                        "settle_launches": settle,
