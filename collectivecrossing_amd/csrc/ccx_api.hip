@@ -153,7 +153,8 @@ int choose_shape(ccx_handle* h) {
     const bool small_tiles = n4 <= 64 * 12;
     // small batches: writer 0 = small outputs, the others share the observation rows (KParams::writer0_small);
     // three writers while 4 waves x tiles still fit the 1024 SIMDs (2048-env C2: 0.54 -> 0.485 us per step); round 3, with
-    // the sim chain at 0.27 us: four writers up to ~280 tiles (2048-env C2 0.773 -> 0.791 of the peak, 1024 envs 0.39 -> 0.41)
+    // the sim chain at 0.27 us and the writer loops compiled per role: four writers up to 160 tiles (1024 envs 0.39 -> 0.41 of
+    // the peak), three beyond (2048 envs: 0.81-0.82 with three, 0.80-0.81 with four)
     // Small tiles beyond that (C2's 4096 x 8: 9.5 store iterations per tile and step): TWO writers split by role
     // as well, as long as 3 waves per tile fit one round (16 wavefronts per CU).  With everything on one writer
     // that wave had 1580 clocks of work per step next to the sim's 1200 and held the tile at ~0.72 us per step --
@@ -161,7 +162,7 @@ int choose_shape(ccx_handle* h) {
     // ~0.70 us: 0.86 -> 0.92 of the HBM peak in one call (round 2; round 1 measured two writers as no gain,
     // but its sim wave was 20 % slower and hid the difference).
     int writers = h->writers > 0 ? h->writers
-                  : small_batch ? ((long long)tiles * 5 <= 1400 ? 4 : (long long)tiles * 4 <= 1100 ? 3 : 2)
+                  : small_batch ? (tiles <= 160 ? 4 : (long long)tiles * 4 <= 1100 ? 3 : 2)
                   : n4 > 64 * 24 ? 3
                   : small_tiles ? ((long long)tiles * 3 <= 16ll * h->num_cus ? 2 : 1) : 2;
     if (writers > 7) writers = 7;
@@ -248,6 +249,7 @@ int choose_shape(ccx_handle* h) {
     k.occ_words = s.occ ? (uint32_t)(occ_bytes / 4u) : 0u;
     k.off_table = (uint32_t)(off_tiles + (size_t)tpb * tile_stride);
     k.stage_slots = slots;
+    k.wp_magic = (uint32_t)((0x100000000ull + (unsigned long long)(p.width + 3) - 1ull) / (unsigned long long)(p.width + 3));
     k.writer_vmcnt = (uint32_t)s.store_throttle;
     k.writer0_small = (h->tun_writer_roles >= 0 ? h->tun_writer_roles != 0 : (small_batch || small_tiles)) && writers >= 2 ? 1u : 0u;
 

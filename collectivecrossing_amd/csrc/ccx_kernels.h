@@ -112,6 +112,7 @@ struct KParams {
     long long pool_stride;               // cursor stride: total_envs mod pool_size, 1 when that is 0
     // tunables (ccx_set_tunable): how the tiles' step schedules are phased, how workgroups map to tiles
     uint32_t pace_phase, tile_map;
+    uint32_t wp_magic;                   // ceil(2^32 / (W + 3)): cell index / row length by one multiply-high (exact below 2^17)
     uint32_t stage_slots;                // slots of the sim -> writer hand-off ring (a power of two, 2..8)
     uint32_t hand_flags;                 // 1: sequence-word hand-off between sim and writer waves (unpaced launches), 0: one barrier per step
     uint32_t writer0_small;              // 1: writer 0 writes the small outputs only, writers 1.. the observation rows

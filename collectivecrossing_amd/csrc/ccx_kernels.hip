@@ -42,6 +42,7 @@
 // multiply per reward (compiled with -ffp-contract=off).  No MFMA on purpose.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "ccx_kernels.h"
@@ -130,6 +131,26 @@ __device__ __forceinline__ void store_obs(v4f v, v4f* dst) {
     // s_nop: the "VMEM store of more than 64 bits followed by a VALU write of its data registers"
     // hazard is the compiler's job for its own instructions; it cannot see into this asm
     asm volatile("global_store_dwordx4 %0, %1, off " CCX_STORE_BITS "\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+#endif
+}
+// The same stores addressed as (wave-uniform base in SGPRs) + (32-bit lane offset) + (immediate < 4096): no 64-bit vector
+// add per store, and the ten per-iteration lane offsets of a writer collapse into three registers.
+template <int IMM>
+__device__ __forceinline__ void store_obs_at(v4f v, const char* base, uint32_t voff) {
+    static_assert(IMM >= 0 && IMM < 4096, "global_store immediate offset");
+#if defined(CCX_PLAIN_STORES) || defined(CCX_BUILTIN_NT_STORES)
+    store_obs(v, reinterpret_cast<v4f*>(const_cast<char*>(base) + voff + IMM));
+#else
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 " CCX_STORE_BITS "\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base), "n"(IMM) : "memory");
+#endif
+}
+template <int IMM>
+__device__ __forceinline__ void store_obs_at(v2f w, const char* base, uint32_t voff) {
+    static_assert(IMM >= 0 && IMM < 4096, "global_store immediate offset");
+#if defined(CCX_PLAIN_STORES) || defined(CCX_BUILTIN_NT_STORES)
+    *reinterpret_cast<v2f*>(const_cast<char*>(base) + voff + IMM) = w;
+#else
+    asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 " CCX_STORE_BITS ::"v"(voff), "v"(w), "s"(base), "n"(IMM) : "memory");
 #endif
 }
 __device__ __forceinline__ void store_obs(float2 v, float2* dst) {   // odd agent counts: 8-byte units

@@ -313,7 +313,7 @@ def test_small_batches_use_full_tiles_with_two_writers_and_equal_the_oracle(orac
     split by role: same results, of course."""
     g = Golden("g8_rollout_c1")
     c, shape, _, _ = _against_oracle(oracle, ccx, g, E=E, K=70, seed=17 + E)
-    assert (shape["lanes_per_wave"], shape["writers_per_tile"], shape["waves_per_block"]) == (64, 4 if E <= 2048 else 2, 1)
+    assert (shape["lanes_per_wave"], shape["writers_per_tile"], shape["waves_per_block"]) == (64, 4 if E <= 1024 else 3 if E <= 2048 else 2, 1)
     assert c["episodes"] > 0
 
 
