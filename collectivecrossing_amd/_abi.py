@@ -111,6 +111,8 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_check_inputs": (C.c_int, [_H]),
     "ccx_set_rng_seed": (C.c_int, [_H, C.c_uint64]),
     "ccx_set_policy_epsilon": (C.c_int, [_H, C.c_double]),
+    "ccx_set_policy_stream": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_uint32]),
+    "ccx_get_policy_stream": (C.c_int, [_H, C.POINTER(C.c_int32), C.c_void_p]),
     "ccx_zero_counters": (C.c_int, [_H]),
     "ccx_read_counters": (C.c_int, [_H, C.POINTER(CcxCounters)]),
     "ccx_counters_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p)]),

@@ -337,6 +337,27 @@ class BatchedCollectiveCrossing:
         -- not numpy's stream; the host classes in ``baseline_policies`` keep that one.  0 = deterministic."""
         check(self._lib.ccx_set_policy_epsilon(self._h, float(epsilon)))
 
+    def set_policy_stream(self, kind: str = "mt19937", seeds=42) -> None:
+        """Where the policies' exploration draws come from (``ccx_set_policy_stream``): ``"counter"`` (default) or
+        ``"mt19937"`` -- every env owns numpy's ``RandomState(seeds[e])`` (one int: the same seed for every env, like one
+        ``create_greedy_policy()`` object per env, seed 42) and the device walks it exactly as the reference's
+        ``get_action`` calls do, so epsilon episodes of the reference replay action for action.  Policy rollouts then
+        run policy and step as separate launches (a validation mode, not the fast path)."""
+        kinds = {"counter": 0, "mt19937": 1}
+        if kind not in kinds:
+            raise ValueError(f"unknown epsilon stream {kind!r}; one of {sorted(kinds)}")
+        if np.ndim(seeds) == 0:
+            check(self._lib.ccx_set_policy_stream(self._h, kinds[kind], None, int(seeds) & 0xFFFFFFFF))
+            return
+        arr = np.ascontiguousarray(np.asarray(seeds, np.uint32).reshape(self.num_envs))
+        check(self._lib.ccx_set_policy_stream(self._h, kinds[kind], arr.ctypes.data, 0))
+
+    def policy_stream_state(self) -> np.ndarray:
+        """u32 [E, 625]: every env's MT19937 generator (key[624], pos) as ``RandomState.get_state()`` has it."""
+        out = np.empty((self.num_envs, 625), np.uint32)
+        check(self._lib.ccx_get_policy_stream(self._h, None, out.ctypes.data))
+        return out
+
     # ------------------------------------------------------------------ counters / timing / shape
     def zero_counters(self) -> None:
         check(self._lib.ccx_zero_counters(self._h))

@@ -629,6 +629,9 @@ void ccx_destroy(ccx_handle* h) {
     (void)hipFree(h->obs_table);
     (void)hipFree(h->cell_info);
     (void)hipFree(h->placement_scratch);
+    (void)hipFree(h->mt_state);
+    (void)hipFree(h->stream_actions);
+    (void)hipFree(h->stream_obs);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
     delete h;
@@ -759,7 +762,9 @@ int ccx_policy_actions(ccx_handle* h, int32_t policy, uint8_t* actions) {
     if (!h || !actions) return fail(CCX_EINVAL, "NULL argument");
     if (policy != CCX_POLICY_GREEDY && policy != CCX_POLICY_WAITING) return fail(CCX_EINVAL, "unknown policy %d", policy);
     CCX_HIP(hipSetDevice(h->device));
-    hipError_t e = ccx::launch_greedy_actions(h->stream, h->kp, h->st, h->cell_info, actions, policy);
+    hipError_t e = h->eps_stream == CCX_EPS_STREAM_MT19937
+        ? ccx::launch_policy_stream_actions(h->stream, h->kp, h->st, h->cell_info, actions, policy, h->mt_state, h->epsilon)
+        : ccx::launch_greedy_actions(h->stream, h->kp, h->st, h->cell_info, actions, policy);
     if (e != hipSuccess) return fail(CCX_EHIP, "policy kernel launch failed: %s", hipGetErrorString(e));
     return CCX_OK;
 }
@@ -843,6 +848,39 @@ int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t
         ko.env_flags = out->env_flags;
         ko.obs_compact = out->obs_compact;
     }
+    if (h->eps_stream == CCX_EPS_STREAM_MT19937 && policy != CCX_POLICY_RANDOM && h->epsilon > 0.0) {
+        // The reference's stream is sequential per env: the policy runs as its own kernel between the steps (policy -> step
+        // -> policy ..., each a launch on the handle's stream) instead of inside the fused one.  Meant for replaying the
+        // reference's epsilon episodes action for action, not for throughput.
+        CCX_HIP(hipSetDevice(h->device));
+        const size_t EN = (size_t)h->E * h->N, L = (size_t)(6 + 4 * h->N);
+        if (!actions_out && !h->stream_actions) CCX_HIP(hipMalloc(&h->stream_actions, EN));
+        for (int s = 0; s < num_steps; ++s) {
+            uint8_t* acts = actions_out ? actions_out + (size_t)s * EN : h->stream_actions;
+            hipError_t e = ccx::launch_policy_stream_actions(h->stream, h->kp, h->st, h->cell_info, acts, policy, h->mt_state,
+                                                             h->epsilon);
+            if (e != hipSuccess) return fail(CCX_EHIP, "policy kernel launch failed: %s", hipGetErrorString(e));
+            ccx::KOut o = ko;
+            if (o.obs) o.obs += (size_t)s * EN * L;
+            if (o.reward) o.reward += (size_t)s * EN;
+            if (o.agent_flags) o.agent_flags += (size_t)s * EN;
+            if (o.env_flags) o.env_flags += (size_t)s * (size_t)h->E;
+            if (o.obs_compact) o.obs_compact += (size_t)s * EN * 4u;
+            // (a step's slice of the observation tensor starts on a 16-byte boundary only if E x N x L x 4 is a multiple of
+            // 16: the others go through an aligned staging slab and a device-to-device copy)
+            float* const obs_dst = o.obs;
+            const bool staged = obs_dst && (reinterpret_cast<uintptr_t>(obs_dst) & 15u);
+            if (staged) {
+                if (!h->stream_obs) CCX_HIP(hipMalloc(&h->stream_obs, EN * L * sizeof(float)));
+                o.obs = h->stream_obs;
+            }
+            const int rc = run_rollout(h, 1, acts, nullptr, auto_reset ? 1 : 0, o);
+            if (rc) return rc;
+            if (staged)
+                CCX_HIP(hipMemcpyAsync(obs_dst, h->stream_obs, EN * L * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        }
+        return CCX_OK;
+    }
     return run_rollout(h, num_steps, nullptr, nullptr, auto_reset ? 1 : 0, ko, policy, actions_out);
 }
 
@@ -886,6 +924,46 @@ int ccx_set_policy_epsilon(ccx_handle* h, double epsilon) {
     if (!(epsilon >= 0.0 && epsilon <= 1.0)) return fail(CCX_EINVAL, "epsilon must be in [0, 1] (got %g)", epsilon);
     const double t = epsilon * 4294967296.0;
     h->kp.eps_thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    h->epsilon = epsilon;
+    return CCX_OK;
+}
+
+int ccx_set_policy_stream(ccx_handle* h, int32_t kind, const uint32_t* seeds, uint32_t seed) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if (kind != CCX_EPS_STREAM_COUNTER && kind != CCX_EPS_STREAM_MT19937)
+        return fail(CCX_EINVAL, "unknown epsilon stream %d", kind);
+    if (kind == CCX_EPS_STREAM_MT19937) {
+        if (h->N > 64) return fail(CCX_EINVAL, "the MT19937 stream walks an env's agents with one 64-lane wave: <= 64 agents");
+        CCX_HIP(hipSetDevice(h->device));
+        if (!h->mt_state) CCX_HIP(hipMalloc(&h->mt_state, (size_t)h->E * ccx::kMtStateWords * sizeof(uint32_t)));
+        uint32_t* seeds_dev = nullptr;
+        if (seeds) {   // (host array: a handful of words per env, staged through the placement scratch's neighbour)
+            CCX_HIP(hipMalloc(&seeds_dev, (size_t)h->E * sizeof(uint32_t)));
+            hipError_t ce = hipMemcpyAsync(seeds_dev, seeds, (size_t)h->E * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
+            if (ce != hipSuccess) {
+                (void)hipFree(seeds_dev);
+                return fail(CCX_EHIP, "seed upload failed: %s", hipGetErrorString(ce));
+            }
+        }
+        hipError_t e = ccx::launch_policy_stream_seed(h->stream, h->mt_state, seeds_dev, seed, h->E);
+        hipError_t se = hipStreamSynchronize(h->stream);      // (the seeds array may be freed by the caller on return)
+        if (seeds_dev) (void)hipFree(seeds_dev);
+        if (e != hipSuccess) return fail(CCX_EHIP, "stream seeding kernel launch failed: %s", hipGetErrorString(e));
+        if (se != hipSuccess) return fail(CCX_EHIP, "stream seeding failed: %s", hipGetErrorString(se));
+    }
+    h->eps_stream = kind;
+    return CCX_OK;
+}
+
+int ccx_get_policy_stream(ccx_handle* h, int32_t* kind, uint32_t* state) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if (kind) *kind = h->eps_stream;
+    if (state) {
+        if (!h->mt_state) return fail(CCX_EINVAL, "no MT19937 stream has been seeded on this handle (ccx_set_policy_stream)");
+        CCX_HIP(hipSetDevice(h->device));
+        CCX_HIP(hipStreamSynchronize(h->stream));
+        CCX_HIP(hipMemcpy(state, h->mt_state, (size_t)h->E * ccx::kMtStateWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
     return CCX_OK;
 }
 

@@ -57,6 +57,11 @@ struct ccx_handle {
     int tun_writer_roles = -1;                                  // -1 = by batch size, 0 = writers share everything, 1 = writer 0 small outputs only
     int tun_hand2 = 1;                                          // sim -> writer hand-off: 0 barrier per step, 1 sequence words in unpaced launches, 2 always
     int tun_max_launch_steps = 0;                               // > 0: cut rollouts into launches of at most this many steps
+    double epsilon = 0.0;                                      // ccx_set_policy_epsilon, as given (the MT19937 stream compares doubles)
+    int eps_stream = 0;                                        // CCX_EPS_STREAM_*: where the policies' exploration draws come from
+    uint32_t* mt_state = nullptr;                              // device u32 [E][625]: one numpy RandomState per env (CCX_EPS_STREAM_MT19937)
+    uint8_t* stream_actions = nullptr;                         // device u8 [E][N]: one step's actions of the unfused policy loop
+    float* stream_obs = nullptr;                               // device f32 [E][N][L]: aligned staging slab of that loop
     bool check_inputs = false;                                 // ccx_set_check_inputs
     unsigned long long* input_errors = nullptr;                // device [2]: bad action bytes, bad order rows
     ccx::LaunchShape shape{};

@@ -203,6 +203,13 @@ hipError_t launch_check_inputs(hipStream_t stream, const uint8_t* actions, const
                                int N, unsigned long long* bad);
 hipError_t launch_greedy_actions(hipStream_t stream, const KParams& p, const KState& st,
                                  const unsigned long long* cell_info, uint8_t* actions, int policy);
+// the reference's own epsilon stream (ccx_policy.hip): per env numpy RandomState = MT19937 key[624] + pos, u32 [E][625]
+constexpr int kMtStateWords = 625;
+hipError_t launch_policy_stream_seed(hipStream_t stream, uint32_t* mt_state, const uint32_t* seeds_dev, uint32_t seed_all,
+                                     int E);
+hipError_t launch_policy_stream_actions(hipStream_t stream, const KParams& p, const KState& st,
+                                        const unsigned long long* cell_info, uint8_t* actions, int policy,
+                                        uint32_t* mt_state, double epsilon);
 hipError_t launch_seeded_placement(hipStream_t stream, const KParams& p, int n, const uint64_t* seeds,
                                    uint64_t seed0, uint8_t* pool_out, const KState& st,
                                    const uint8_t* env_mask, uint8_t* scratch_xy, int max_tries,

@@ -277,11 +277,40 @@ int ccx_set_rng_seed(ccx_handle* h, uint64_t seed);
  *     explore  iff  u < floor(epsilon * 2^32)                (epsilon = 1: 2^32 - 1)
  *     action   =  the ((mix(u + 0x9E3779B9) * count) >> 32)-th valid action in ascending order, count = #valid
  * pinned by the oracle's restatement (ccxo_set_policy_epsilon).  0 (the default) = the deterministic policies.
- * The host classes of collectivecrossing_amd/baseline_policies.py keep the reference's own RandomState stream.
+ * The host classes of collectivecrossing_amd/baseline_policies.py keep the reference's own RandomState stream, and so does
+ * the device with ccx_set_policy_stream(CCX_EPS_STREAM_MT19937) (below).
  * ccx_policy_actions honours it as well (same draws: a loop of ccx_policy_actions + ccx_step takes the actions
  * ccx_rollout_policy takes); ccx_greedy_actions is always epsilon = 0.
  */
 int ccx_set_policy_epsilon(ccx_handle* h, double epsilon);
+/*
+ * Where the exploration draws of the scripted policies come from.
+ *   CCX_EPS_STREAM_COUNTER (default): the counter-based draws documented above.
+ *   CCX_EPS_STREAM_MT19937: the REFERENCE's own stream.  The reference's policies hold one
+ *     `np.random.RandomState(seed)` (greedy_policy.py:31, waiting_policy.py:31; create_greedy_policy /
+ *     create_waiting_policy seed it with 42, :452-465) and every get_action call draws from it in turn --
+ *     `random_state.random() < randomness_factor` (:49), then `random_state.choice(valid_actions)` (:57) -- for the
+ *     agents of env.agents in index order (scripts/run_greedy_policy_demo.py:67-109).  With this stream every env owns
+ *     one such generator (numpy's legacy MT19937: init_genrand seeding, 53-bit doubles from two outputs, choice =
+ *     masked rejection on 32-bit outputs, a one-entry list draws nothing), seeded here with seeds[e] (HOST array u32 [E])
+ *     or, seeds NULL, with `seed` for every env (= one policy object per env, as the reference's callers have), and
+ *     walked on the device by one wave per env: an epsilon episode of the reference replays ACTION FOR ACTION
+ *     (tests: the reference-recorded g11_epsilon_policy_* episodes).  epsilon is compared as the double given to
+ *     ccx_set_policy_epsilon.  The stream is sequential per env, so
+ *       - ccx_policy_actions draws from it (every call advances the generators; epsilon 0 draws nothing);
+ *       - ccx_rollout_policy (greedy / waiting, epsilon > 0) runs policy -> step -> policy ... as separate launches
+ *         on the handle's stream instead of the fused kernel: the mode for replaying / validating against the
+ *         reference, not for throughput (any batch size works; the fused kernel keeps the counter-based draws);
+ *       - the generators run on across episodes (auto_reset), as a policy object of the reference does;
+ *       - ccx_greedy_actions and CCX_POLICY_RANDOM never touch them.
+ *     Calling it again re-seeds.  Synchronous.
+ * ccx_get_policy_stream: the kind in effect and (state != NULL, host u32 [E][625]) every env's generator as numpy's
+ * RandomState.get_state() has it: key[624] then pos.  Synchronises the handle's stream.
+ */
+#define CCX_EPS_STREAM_COUNTER 0
+#define CCX_EPS_STREAM_MT19937 1
+int ccx_set_policy_stream(ccx_handle* h, int32_t kind, const uint32_t* seeds, uint32_t seed);
+int ccx_get_policy_stream(ccx_handle* h, int32_t* kind, uint32_t* state);
 
 /*
  * Opt-in input validation for the array API (the dict API validates on the host).  The reference raises

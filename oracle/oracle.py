@@ -84,6 +84,12 @@ def lib() -> C.CDLL:
         L.ccxo_set_policy_epsilon.restype = None
         L.ccxo_greedy_actions.argtypes = [PP, C.c_int32] + [V] * 6
         L.ccxo_greedy_actions.restype = None
+        L.ccxo_mt_seed_streams.argtypes = [V, C.c_int32, V]
+        L.ccxo_mt_seed_streams.restype = None
+        L.ccxo_mt_probe.argtypes = [C.c_uint32, C.c_int32, V, V, V, C.c_int32, V]
+        L.ccxo_mt_probe.restype = None
+        L.ccxo_set_policy_stream_mt19937.argtypes = [V, C.c_double]
+        L.ccxo_set_policy_stream_mt19937.restype = None
         _lib = L
     return _lib
 
@@ -112,6 +118,19 @@ def rng_probe(seed: int, n: int, low: int, high: int):
     r64, r32, b = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.int64)
     lib().ccxo_rng_probe(seed, n, r64.ctypes.data, r32.ctypes.data, low, high, b.ctypes.data)
     return r64, r32, b
+
+
+MT_STATE_WORDS = 625      # ccxo_mt19937: key[624] + pos
+
+
+def mt_probe(seed: int, n: int, counts):
+    """n raw 32-bit words, n `random()` doubles and n `choice` indices (list lengths cycling through `counts`) of the
+    oracle's restatement of numpy's RandomState(seed) -- each from a freshly seeded generator."""
+    raw, dbl, picks = np.empty(n, np.uint32), np.empty(n, np.float64), np.empty(n, np.int32)
+    counts = np.ascontiguousarray(counts, np.int32)
+    lib().ccxo_mt_probe(C.c_uint32(int(seed)), n, _p(raw, np.uint32), _p(dbl, np.float64), _p(counts, np.int32),
+                        len(counts), _p(picks, np.int32))
+    return raw, dbl, picks
 
 
 def seeded_placements(params: CcxParams, seeds, max_tries: int = 1 << 20) -> np.ndarray:
@@ -145,6 +164,8 @@ class OracleBatch:
         self.episode = np.zeros((E,), np.int32)
         self.pool: np.ndarray | None = None
         self.counters = CcxCounters()
+        self._mt: np.ndarray | None = None          # [E, 625] u32: one numpy-RandomState restatement per env
+        self._mt_epsilon = 0.0
 
     # -- state ------------------------------------------------------------------------------
     def set_state(self, x=None, y=None, active=None, terminated=None, truncated=None,
@@ -190,11 +211,27 @@ class OracleBatch:
         """randomness_factor of the greedy / waiting policies in rollout_greedy (process-wide in the oracle)."""
         lib().ccxo_set_policy_epsilon(C.c_double(float(epsilon)))
 
+    def set_policy_stream_mt19937(self, seeds, epsilon: float) -> None:
+        """The reference's own epsilon stream: env e draws from `np.random.RandomState(seeds[e])` (one int = every env
+        the same seed, as one policy object per env has in the reference), consumed by env.agents in index order.
+        `None` switches back to the counter-based draws."""
+        if seeds is None:
+            self._mt = None
+            return
+        seeds = np.broadcast_to(np.asarray(seeds, np.uint32), (self.E,)).copy()
+        self._mt = np.zeros((self.E, MT_STATE_WORDS), np.uint32)
+        lib().ccxo_mt_seed_streams(_p(self._mt, np.uint32), self.E, _p(seeds, np.uint32))
+        self._mt_epsilon = float(epsilon)
+
+    def _bind_stream(self) -> None:   # (process-wide pointer in the oracle: set it for every call)
+        lib().ccxo_set_policy_stream_mt19937(_p(self._mt, np.uint32), C.c_double(self._mt_epsilon))
+
     def policy_actions(self, policy: str = "greedy", with_epsilon: bool = False) -> np.ndarray:
         """GreedyPolicy / WaitingPolicy action of every live agent, u8 [E, N]: epsilon 0, or (with_epsilon) with
         the exploration draws of set_policy_epsilon, as ccx_policy_actions does."""
         out = np.empty((self.E, self.N), np.uint8)
         if with_epsilon:
+            self._bind_stream()
             lib().ccxo_policy_actions_eps(C.byref(self.params), self.POLICIES[policy], self.E, int(self.env_offset),
                                           _p(self.x, np.int32), _p(self.y, np.int32),
                                           _p(self.active, np.uint8), _p(self.terminated, np.uint8),
@@ -263,6 +300,7 @@ class OracleBatch:
         af = np.empty((K, E, N), np.uint8)
         ef = np.empty((K, E), np.uint8)
         pool = self.pool
+        self._bind_stream()
         lib().ccxo_rollout_policy(C.byref(self.params), self.POLICIES[policy], E, self.env_offset, self.total_envs,
                                   _p(self.x, np.int32), _p(self.y, np.int32), _p(self.active, np.uint8),
                                   _p(self.terminated, np.uint8), _p(self.truncated, np.uint8),
