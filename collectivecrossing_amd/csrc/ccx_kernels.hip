@@ -294,10 +294,11 @@ constexpr int kObsBatch = 5;       // LDS reads issued back to back before their
 //        OCC = false: all-pairs compare through the xch tile (grids whose tables exceed LDS).
 // wave index in block -> role = wib / tiles_per_block (0 = sim, 1.. = writer), tile = wib % tpb.
 // ---------------------------------------------------------------------------------------------
-#ifdef CCX_TSTAMPS   // diagnostic (profiles/scratch/tstamps.py): raw s_memtime at fixed points of tile 0's sim wave
-#define CCX_T(q) do { if (counters && blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_; \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-    counters[8 + (q)] = t_; } } while (0)
+#ifdef CCX_TSTAMPS   // diagnostic (profiles/scratch/tstamps.py): raw s_memrealtime (10-ns ticks) at fixed points of tile 0's waves
+#define CCX_T(q) do { if (rollout_kernarg_tail().counters && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && \
+                          ((q) >= 7 || threadIdx.x == 0)) { unsigned long long t_; \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    rollout_kernarg_tail().counters[8 + (q)] = t_; } } while (0)
 #else
 #define CCX_T(q) do { } while (0)
 #endif
@@ -332,6 +333,21 @@ __device__ __forceinline__ KParamsC& rollout_kernarg_params() {
 #else
     static KParams host_dummy{};
     return *(KParamsC*)(uintptr_t)&host_dummy;
+#endif
+}
+// Reading fields where they are used makes the kernel entry a CHAIN of scalar-cache misses (seven 64-byte lines, each
+// first touch a memory round trip of its own: a single-step launch spent ~1.6 us before its first global load).  One
+// dword of every line is requested at entry, all at once, and waited for once; the values are never used, the lines are in
+// the scalar cache for the loads that follow.
+__device__ __forceinline__ void rollout_kernarg_prefetch() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(sizeof(KParams) + sizeof(KernargTail) <= 7 * 64, "one s_load per 64-byte line of the explicit arguments");
+    uint32_t d0, d1, d2, d3, d4, d5, d6;
+    asm volatile("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\t"
+                 "s_load_dword %3, %7, 0xc0\n\ts_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\t"
+                 "s_load_dword %6, %7, 0x180\n\ts_waitcnt lgkmcnt(0)"   // (the compiler must not reuse a destination in flight)
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6)
+                 : "s"(__builtin_amdgcn_kernarg_segment_ptr()));
 #endif
 }
 __device__ __forceinline__ KernargTailC& rollout_kernarg_tail() {

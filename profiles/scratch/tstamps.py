@@ -23,9 +23,11 @@ acts = torch.randint(0, 5, (64, E, N), dtype=torch.uint8, device=env.device)
 p = C.c_void_p()
 env._lib.ccx_counters_device_ptr(env._h, C.byref(p))
 names = ["entry->tables built", "syncthreads", "state/pool/action loads issued", "step loop", "pace vote", "state stores + counters"]
+traj = {K: env.alloc_rollout(K) for K in (1, 16, 64)}
 for K in (1, 1, 1, 16, 64):
-    env.rollout(acts[:K], auto_reset=True)
+    env.rollout(acts[:K], auto_reset=True, out=traj[K])
     env.synchronize()
-    c = _device_view_i64(p.value, 16, env.device).cpu().tolist()[8:15]
-    print("K", K, "kernel", round(env.last_launch_ms() * 1000, 1), "us; ticks:",
-          {n: c[i + 1] - c[i] for i, n in enumerate(names)}, "total", c[6] - c[0])
+    c = _device_view_i64(p.value, 16, env.device).cpu().tolist()[8:16]
+    print("K", K, "kernel", round(env.last_launch_ms() * 1000, 2), "us; 10-ns ticks:",
+          {n: c[i + 1] - c[i] for i, n in enumerate(names)}, "sim wave total", c[6] - c[0],
+          "last writer of tile 0 done at", c[7] - c[0])
