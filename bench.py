@@ -372,6 +372,35 @@ def secondary_figures(torch, env, actions, chunk: int) -> dict:
     us = e0.elapsed_time(e1) * 1e3 / reps
     out["step_k1"] = {"us_per_step": us, "env_steps_per_sec": E / (us * 1e-6),
                       "what": f"{reps} back-to-back ccx_step launches (K = 1, full outputs), eager"}
+    # The eager figure is what the HOST can issue (Python + hipLaunchKernel per call); captured into a HIP graph the
+    # same launches run back to back on the device: the kernel's own single-step latency.
+    try:
+        side = torch.cuda.Stream(device=dev)
+        env.use_stream(side)
+        with torch.cuda.stream(side):
+            env.step(actions[0])
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            n = min(100, int(actions.shape[0]))
+            with torch.cuda.graph(graph, stream=side):
+                for k in range(n):
+                    env.step(actions[k])
+            graph.replay()
+            side.synchronize()
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record(side)
+            for _ in range(10):
+                graph.replay()
+            g1.record(side)
+            side.synchronize()
+        us_g = g0.elapsed_time(g1) * 1e3 / (10 * n)
+        out["step_k1_graph"] = {"us_per_step": us_g, "env_steps_per_sec": E / (us_g * 1e-6),
+                                "what": f"{n} ccx_step launches (K = 1, full outputs) captured into one HIP graph, replayed"}
+        del graph
+    except Exception as exc:   # (a secondary figure must never cost the bench line)
+        out["step_k1_graph"] = {"error": repr(exc)}
+    finally:
+        env.use_stream(torch.cuda.current_stream(dev))
     return out
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r03_c25
+OUT=$ROOT/gpurun_out/r03_c26
 mkdir -p $OUT
 cd $ROOT
 timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q > $OUT/pytest.txt 2>&1 || { tail -60 $OUT/pytest.txt; exit 1; }

@@ -63,6 +63,7 @@ def test_bench_line_has_the_contract_fields_and_adds_up():
     assert d["rccl_ranks"] == 0 and d["collective_backend"] is None and d["per_rank_env_steps_per_sec"][0] >= d["value"] * 0.999
     sec = d["secondary"]
     assert 0.1 < sec["no_obs"]["us_per_env_step"] < 5 and 1 < sec["step_k1"]["us_per_step"] < 100
+    assert 1 < sec["step_k1_graph"]["us_per_step"] < 100          # (the same launches without the host in the loop)
 
 
 def test_bench_with_a_pace_cache_says_so(tmp_path):

@@ -587,3 +587,30 @@ def test_launch_mode_boundaries_against_the_oracle(oracle, ccx, K, pace, obs):
         assert paced == (pace != -1)
     finally:
         env.close()
+
+
+def test_one_step_launches_take_liveness_from_the_state_at_kernel_entry(ccx):
+    """Regression (round 3): writer 0 used to read terminated / truncated from the state arrays BEHIND the prologue's
+    barrier, while the sim wave of a one-step launch may already be writing the post-step state back -- once the prologue
+    got faster, a step that truncates everybody reported random agents as "not live before the step" (no reward /
+    truncated entry in the dict API).  Every wave now reads the pair in front of the barrier.  300 single-step launches
+    from the last step before truncation, tiny batches (the sim wave finishes first there) and a full one."""
+    from collectivecrossing_amd import configs as C
+    AF_TRUNC, AF_LIVE = 2, 4
+    for E, reps in ((1, 200), (3, 60), (4096, 40)):
+        cfg = C.CollectiveCrossingConfig(width=10, height=8, division_y=4, tram_door_left=4, tram_door_right=5, tram_length=8,
+                                         num_boarding_agents=1, num_exiting_agents=1, exiting_destination_area_y=1,
+                                         boarding_destination_area_y=7,
+                                         truncated_config=C.MaxStepsTruncatedConfig(max_steps=65535))
+        env = ccx(cfg, E)
+        env.reset(np.arange(E, dtype=np.uint64))
+        st = env.get_state()
+        acts = np.full((E, 2), 4, np.uint8)
+        for rep in range(reps):
+            env.set_state(x=st["x"], y=st["y"], active=np.ones((E, 2), np.uint8), terminated=np.zeros((E, 2), np.uint8),
+                          truncated=np.zeros((E, 2), np.uint8), step_count=np.full(E, 65534, np.int32))
+            r = env.step(acts, want_obs=bool(rep & 1))
+            af = r.agent_flags.cpu().numpy()
+            assert ((af & (AF_TRUNC | AF_LIVE)) == (AF_TRUNC | AF_LIVE)).all(), (E, rep, af[:2])
+            assert (r.env_flags.cpu().numpy() & 2).all()
+        env.close()
