@@ -126,7 +126,7 @@ int choose_shape(ccx_handle* h) {
     // 3 waves x tiles stays near the 1024 SIMDs: C2 geometry, us per env-step, full tiles + 2 writers vs the
     // half-empty single-writer tiles chosen before: 1024 envs 0.53 vs 0.58, 2048 envs 0.54 vs 0.59 (0.63 vs
     // 0.58 of the HBM peak), 3072 envs 0.63 vs 0.72 (0.81 vs 0.70).
-    bool small_batch = false;
+    bool small_batch = false, half_tiles = false;
     if (h->lanes_per_wave == 0 && h->writers != 1 && h->waves_per_block == 0) {
         const long long full_tiles = (h->E + max_ew - 1) / max_ew;
         const int full_n4 = max_ew * h->N * (3 + 2 * h->N) / ((h->N % 2 == 0) ? 2 : 1);
@@ -135,10 +135,22 @@ int choose_shape(ccx_handle* h) {
             const size_t cells_ = (size_t)(h->params.width + 3) * (size_t)(h->params.height + 3);
             const size_t msz_ = (glog == 6) ? 8u : 4u;
             const size_t units_ = (size_t)max_ew * h->N * (3 + 2 * h->N);
-            if (up(cells_ * 8u) + up(ccx::tile_head_bytes(16) + 2u * 1056u + up((size_t)max_ew * 2u * (cells_ + 1u) * msz_)) +
+            // (with the writer slots of the writer count chosen below -- up to four for small batches: a check against
+            // two let a 6 x 16 grid with one agent per env through whose full tile then lost its occupancy tables, and
+            // with them the in-kernel policies; found by the round-3 hypothesis soak)
+            const size_t wslots_ = (size_t)(h->writers > 0 ? h->writers : 4) * 1056u;
+            if (up(cells_ * 8u) + up(ccx::tile_head_bytes(16) + wslots_ + up((size_t)max_ew * 2u * (cells_ + 1u) * msz_)) +
                     up((units_ + 2u) * 2u) <= 96u * 1024u) {
                 small_batch = true;
                 ew = max_ew;
+                // Up to 128 full tiles (C2 geometry: 1024 envs) half the CUs would stand idle: HALF tiles with four writers
+                // each put a tile on every CU and halve each writer's share (round 3, us per env-step with full outputs:
+                // 1024 envs 0.355 vs 0.398-0.402 with full tiles and 3-4 writers, 512 envs 0.353 vs 0.395).  What remains
+                // is the step's own latency chain sim -> hand-off -> writer (~0.35 us), not bytes.
+                if (full_tiles <= 128 && max_ew >= 2 && h->writers == 0) {
+                    ew = max_ew / 2;
+                    half_tiles = true;
+                }
             }
         }
     }
@@ -162,7 +174,7 @@ int choose_shape(ccx_handle* h) {
     // ~0.70 us: 0.86 -> 0.92 of the HBM peak in one call (round 2; round 1 measured two writers as no gain,
     // but its sim wave was 20 % slower and hid the difference).
     int writers = h->writers > 0 ? h->writers
-                  : small_batch ? (tiles <= 160 ? 4 : (long long)tiles * 4 <= 1100 ? 3 : 2)
+                  : small_batch ? (half_tiles || tiles <= 160 ? 4 : (long long)tiles * 4 <= 1100 ? 3 : 2)
                   : n4 > 64 * 24 ? 3
                   : small_tiles ? ((long long)tiles * 3 <= 16ll * h->num_cus ? 2 : 1) : 2;
     if (writers > 7) writers = 7;

@@ -307,13 +307,15 @@ def test_steady_state_launches_have_no_outliers(ccx):
     assert over <= 3 and ms.max() < 1.25 * med, (over, ms.max() / med, sorted(ms)[-3:], st)
 
 
-@pytest.mark.parametrize("E", [1024, 2048, 3072])
+@pytest.mark.parametrize("E", [512, 1024, 2048, 3072])
 def test_small_batches_use_full_tiles_with_two_writers_and_equal_the_oracle(oracle, ccx, E):
-    """Below the memory-bound regime the default shape is full 64-lane tiles with two to four writer waves each,
-    split by role: same results, of course."""
+    """Below the memory-bound regime the default shape is full 64-lane tiles with two to three writer waves each, split
+    by role -- half tiles with four writers while full ones would leave half the CUs idle: same results, of
+    course."""
     g = Golden("g8_rollout_c1")
     c, shape, _, _ = _against_oracle(oracle, ccx, g, E=E, K=70, seed=17 + E)
-    assert (shape["lanes_per_wave"], shape["writers_per_tile"], shape["waves_per_block"]) == (64, 4 if E <= 1024 else 3 if E <= 2048 else 2, 1)
+    assert (shape["lanes_per_wave"], shape["writers_per_tile"], shape["waves_per_block"]) == (
+        (32, 4, 1) if E <= 1024 else (64, 3, 1) if E <= 2048 else (64, 2, 1))
     assert c["episodes"] > 0
 
 
@@ -613,4 +615,35 @@ def test_one_step_launches_take_liveness_from_the_state_at_kernel_entry(ccx):
             af = r.agent_flags.cpu().numpy()
             assert ((af & (AF_TRUNC | AF_LIVE)) == (AF_TRUNC | AF_LIVE)).all(), (E, rep, af[:2])
             assert (r.env_flags.cpu().numpy() & 2).all()
+        env.close()
+
+
+@pytest.mark.parametrize("E", [257, 64, 1000])
+def test_small_batches_of_tall_grids_keep_the_occupancy_tables(oracle, ccx, E):
+    """Regression (round-3 hypothesis soak): the small-batch shape checked the LDS need of a full 64-lane tile against
+    TWO writer slots while the writer rule chose four -- a 6 x 16 grid with one agent per env (64 envs per tile, 88 KB of
+    occupancy tables) passed the check, lost the tables and refused every in-kernel policy rollout.  The check now uses
+    the writer count that will be chosen; such batches fall back to smaller tiles and keep the tables."""
+    from collectivecrossing_amd import configs as C
+    from collectivecrossing_amd.params import lower_config
+    from collectivecrossing_amd.reset import build_reset_pool
+
+    cfg = C.CollectiveCrossingConfig(width=6, height=16, division_y=2, tram_door_left=0, tram_door_right=1, tram_length=4,
+                                     num_boarding_agents=0, num_exiting_agents=1, exiting_destination_area_y=0,
+                                     boarding_destination_area_y=10, truncated_config=C.MaxStepsTruncatedConfig(max_steps=30))
+    pool = build_reset_pool(cfg, 3, 37)
+    ob, env = oracle.OracleBatch(lower_config(cfg), E), ccx(cfg, E)
+    try:
+        for b in (ob, env):
+            b.set_reset_pool(pool)
+            b.reset_from_pool()
+        for policy in ("greedy", "waiting"):
+            o_act, o_obs, o_rew, o_af, o_ef = ob.rollout_greedy(40, auto_reset=True, policy=policy)
+            res, acts = env.rollout_greedy(40, auto_reset=True, policy=policy)
+            np.testing.assert_array_equal(acts.cpu().numpy(), o_act)
+            np.testing.assert_array_equal(res.agent_flags.cpu().numpy(), o_af)
+            np.testing.assert_array_equal(res.obs.cpu().numpy().view(np.uint32), o_obs.view(np.uint32))
+            np.testing.assert_array_equal(res.reward.cpu().numpy().view(np.uint64), o_rew.view(np.uint64))
+        assert env.counters() == ob.counters.as_dict()
+    finally:
         env.close()
