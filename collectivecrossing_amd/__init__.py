@@ -9,7 +9,7 @@ package.
 
 from .configs import CollectiveCrossingConfig  # noqa: F401
 
-__version__ = "0.3.0"
+__version__ = "0.4.0"
 __all__ = ["CollectiveCrossingConfig", "CollectiveCrossingEnv", "BatchedCollectiveCrossing", "VectorCollectiveCrossing",
            "BatchedMultiAgentEnv"]
 

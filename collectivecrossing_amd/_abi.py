@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # ccx_status
 OK, EINVAL, ENOMEM, EHIP, ENODEVICE = 0, -1, -2, -3, -4

@@ -528,7 +528,7 @@ int ccx_abi_version(void) { return CCX_ABI_VERSION; }
 
 const char* ccx_build_info(void) {
     static char buf[128];
-    snprintf(buf, sizeof(buf), "libccx 0.3.0 abi %d gfx950 hip %d.%d", CCX_ABI_VERSION,
+    snprintf(buf, sizeof(buf), "libccx 0.4.0 abi %d gfx950 hip %d.%d", CCX_ABI_VERSION,
              HIP_VERSION_MAJOR, HIP_VERSION_MINOR);
     return buf;
 }

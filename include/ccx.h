@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CCX_ABI_VERSION 3
+#define CCX_ABI_VERSION 4
 
 typedef enum ccx_status {
     CCX_OK = 0,
