@@ -511,8 +511,9 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
            E=st.sampled_from([1, 5, 64, 130, 257]), K=st.integers(1, 48),
            mode=st.sampled_from(["actions", "actions", "greedy", "waiting", "random"]), compact=st.booleans(),
            writers=st.sampled_from([0, 0, 1, 2, 3, 4]), roles=st.sampled_from([-1, -1, 0, 1]),
-           hand2=st.sampled_from([1, 1, 0, 2]), full_tiles=st.booleans(), eps=st.sampled_from([0.0, 0.0, 0.1, 0.5, 1.0]))
-    def run(cfg, seed, E, K, mode, compact, writers, roles, hand2, full_tiles, eps):
+           hand2=st.sampled_from([1, 1, 0, 2]), full_tiles=st.booleans(), eps=st.sampled_from([0.0, 0.0, 0.1, 0.5, 1.0]),
+           mt=st.sampled_from([False, False, True]))
+    def run(cfg, seed, E, K, mode, compact, writers, roles, hand2, full_tiles, eps, mt):
         p = lower_config(cfg)
         N = p.num_boarding + p.num_exiting
         rng = np.random.default_rng(seed)
@@ -545,9 +546,15 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
                 env.set_rng_seed(seed * 2654435761 + 7)
                 oracle.OracleBatch.set_policy_epsilon(eps)      # epsilon-greedy / -waiting (no effect on "random")
                 env.set_policy_epsilon(eps)
+                if mt and mode != "random":                      # the reference's own stream: a numpy RandomState per env
+                    mt_seeds = (np.arange(E, dtype=np.uint32) * np.uint32(40503) + np.uint32(seed)) if seed & 2 else seed
+                    ob.set_policy_stream_mt19937(mt_seeds, eps)
+                    env.set_policy_stream("mt19937", mt_seeds)
                 o_act, o_obs, o_rew, o_af, o_ef = ob.rollout_greedy(K, auto_reset=True, policy=mode)
                 res, acts = env.rollout_greedy(K, auto_reset=True, policy=mode, out=out)
                 np.testing.assert_array_equal(_np(acts), o_act)
+                if mt and mode != "random":
+                    np.testing.assert_array_equal(env.policy_stream_state(), ob._mt)
             np.testing.assert_array_equal(_np(res.agent_flags), o_af)
             np.testing.assert_array_equal(_np(res.env_flags), o_ef)
             got_obs = _np(env.expand_observations(res.obs_compact)) if compact else _np(res.obs)
