@@ -82,6 +82,7 @@ class BatchedCollectiveCrossing:
         self._h = handle
         self._pool: torch.Tensor | None = None
         self._step_bufs: StepResult | None = None
+        self._step_out_cache: dict = {}
         self._rollouts_with_obs = 0
         if check_inputs is None:
             check_inputs = os.environ.get("CCX_CHECK_INPUTS", "0") not in ("", "0")
@@ -258,12 +259,19 @@ class BatchedCollectiveCrossing:
         b = self._step_bufs
         if want_compact and b.obs_compact is None:
             b.obs_compact = self._new((E, N, 4), torch.float32)
-        so = _abi.CcxStepOut(_ptr(b.obs if want_obs else None).value, _ptr(b.reward).value,
-                             _ptr(b.agent_flags).value, _ptr(b.env_flags).value,
-                             _ptr(b.obs_compact if want_compact else None).value)
-        check(self._lib.ccx_step(self._h, _ptr(a), _ptr(o), C.byref(so)))
-        return StepResult(b.obs if want_obs else None, b.reward, b.agent_flags, b.env_flags,
-                          b.obs_compact if want_compact else None)
+        # (the output buffers are static: their ccx_step_out struct and the result tuple are built once per output
+        # selection -- this is the per-step path of a policy-in-the-loop caller, a few microseconds end to end)
+        key = (bool(want_obs), bool(want_compact))
+        cached = self._step_out_cache.get(key)
+        if cached is None:
+            so = _abi.CcxStepOut(_ptr(b.obs if want_obs else None).value, _ptr(b.reward).value,
+                                 _ptr(b.agent_flags).value, _ptr(b.env_flags).value,
+                                 _ptr(b.obs_compact if want_compact else None).value)
+            cached = (so, C.byref(so), StepResult(b.obs if want_obs else None, b.reward, b.agent_flags, b.env_flags,
+                                                  b.obs_compact if want_compact else None))
+            self._step_out_cache[key] = cached
+        check(self._lib.ccx_step(self._h, a.data_ptr(), None if o is None else o.data_ptr(), cached[1]))
+        return cached[2]
 
     def alloc_rollout(self, num_steps: int, want_obs: bool = True, want_compact: bool = False) -> RolloutResult:
         K, E, N = num_steps, self.num_envs, self.num_agents
