@@ -866,7 +866,17 @@ int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t
         // reference's epsilon episodes action for action, not for throughput.
         CCX_HIP(hipSetDevice(h->device));
         const size_t EN = (size_t)h->E * h->N, L = (size_t)(6 + 4 * h->N);
-        if (!actions_out && !h->stream_actions) CCX_HIP(hipMalloc(&h->stream_actions, EN));
+        // (the loop's scratch buffers are allocated on first use: never inside a stream capture)
+        const bool misaligned_steps = ko.obs && ((EN * L * sizeof(float)) & 15u) && num_steps > 1;
+        if ((!actions_out && !h->stream_actions) || (misaligned_steps && !h->stream_obs)) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess) (void)hipGetLastError();
+            else if (cap != hipStreamCaptureStatusNone)
+                return fail(CCX_EINVAL, "the stepwise policy loop allocates scratch buffers on first use: run one eager "
+                            "policy rollout of this shape before capturing it into a graph");
+            if (!actions_out && !h->stream_actions) CCX_HIP(hipMalloc(&h->stream_actions, EN));
+            if (misaligned_steps && !h->stream_obs) CCX_HIP(hipMalloc(&h->stream_obs, EN * L * sizeof(float)));
+        }
         for (int s = 0; s < num_steps; ++s) {
             uint8_t* acts = actions_out ? actions_out + (size_t)s * EN : h->stream_actions;
             hipError_t e = ccx::launch_policy_stream_actions(h->stream, h->kp, h->st, h->cell_info, acts, policy, h->mt_state,
@@ -883,7 +893,7 @@ int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t
             float* const obs_dst = o.obs;
             const bool staged = obs_dst && (reinterpret_cast<uintptr_t>(obs_dst) & 15u);
             if (staged) {
-                if (!h->stream_obs) CCX_HIP(hipMalloc(&h->stream_obs, EN * L * sizeof(float)));
+                if (!h->stream_obs) return fail(CCX_EINVAL, "obs buffer must be 16-byte aligned");   // (a misaligned BASE)
                 o.obs = h->stream_obs;
             }
             const int rc = run_rollout(h, 1, acts, nullptr, auto_reset ? 1 : 0, o);
