@@ -9,6 +9,7 @@ from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from collectivecrossing_amd import BatchedCollectiveCrossing, CollectiveCrossingConfig, CollectiveCrossingEnv  # noqa: E402
@@ -52,6 +53,16 @@ batch.set_policy_epsilon(0.1)
 traj, chosen = batch.rollout_greedy(K, auto_reset=True, out=traj)
 print("epsilon-greedy rollout: mean live reward", float(traj.reward[traj.agent_flags & 4 != 0].mean()))
 batch.set_policy_epsilon(0.0)
+
+# 3c. the reference's OWN exploration stream: one numpy RandomState(42) per env, walked on the device exactly as
+#     create_greedy_policy(0.1).get_action(...) consumes it -- a small evaluation batch replays the reference action for action
+small_batch = BatchedCollectiveCrossing(config, num_envs=16)
+small_batch.reset(np.arange(16, dtype=np.uint64))                   # reset(seed=e) for env e, on the device
+small_batch.set_policy_epsilon(0.1)
+small_batch.set_policy_stream("mt19937", 42)
+ev, ev_actions = small_batch.rollout_greedy(50)
+print("reference-stream epsilon-greedy: actions of env 0, first 3 steps", ev_actions[:3, 0].tolist())
+small_batch.close()
 
 # 4. consumers on the GPU: (x, y, type, active) once per agent instead of the N-fold rows; expand what you sample
 del traj
