@@ -847,9 +847,6 @@ int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t
     if (num_steps < 1) return fail(CCX_EINVAL, "num_steps must be >= 1");
     if (policy != CCX_POLICY_GREEDY && policy != CCX_POLICY_WAITING && policy != CCX_POLICY_RANDOM)
         return fail(CCX_EINVAL, "unknown policy %d", policy);
-    if (!h->shape.occ && policy != CCX_POLICY_RANDOM)
-        return fail(CCX_EINVAL, "policy rollouts need the LDS occupancy tables, which do not fit for this "
-                    "grid / envs-per-wave; drive ccx_step with ccx_greedy_actions instead");
     if (auto_reset && (!h->pool || h->pool_size <= 0))
         return fail(CCX_EINVAL, "auto_reset needs a reset pool (ccx_set_reset_pool)");
     ccx::KOut ko{};
@@ -903,6 +900,9 @@ int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t
         }
         return CCX_OK;
     }
+    if (!h->shape.occ && policy != CCX_POLICY_RANDOM)   // (the stepwise loop above uses the stand-alone policy kernel: any shape)
+        return fail(CCX_EINVAL, "policy rollouts need the LDS occupancy tables, which do not fit for this "
+                    "grid / envs-per-wave; drive ccx_step with ccx_greedy_actions instead");
     return run_rollout(h, num_steps, nullptr, nullptr, auto_reset ? 1 : 0, ko, policy, actions_out);
 }
 

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(64) void policy_stream_kernel(const KParams p, cons
     uint32_t* g = mt_state + (size_t)env * (kMtWords + 1);
     for (int i = lane; i < kMtWords; i += 64) key[i] = g[i];
     int pos = (int)g[kMtWords];                                   // wave-uniform
+    pos = pos < 0 || pos > kMtWords ? kMtWords : pos;             // (a state this library did not write: twist first)
     __syncthreads();
 
     const bool agent = lane < p.N;
