@@ -222,12 +222,20 @@ int choose_shape(ccx_handle* h) {
     const size_t lds_cu = 160u * 1024u;
     size_t off_ws = 0, off_occ = 0, tile_stride = 0, total = 0;
     uint32_t slots = ccx::kMaxStageSlots;
+    // Small batches (unpaced, writers split by role): a second staging slot per writer lets a row writer take TWO steps
+    // per iteration whenever the sim wave is that far ahead (ccx_rollout_body.inc) -- if the LDS has the room.
+    size_t wsw = 1;
     auto lay_out = [&](uint32_t nslots, int tiles_pb, bool with_occ) {
         off_ws = ccx::tile_head_bytes(nslots);                   // xch + hand-off words + stage ring
-        off_occ = off_ws + (size_t)writers * 1056u;              // WSlot per writer
+        off_occ = off_ws + (size_t)writers * wsw * 1056u;        // WSlot(s) per writer
         tile_stride = up16(off_occ + (with_occ ? occ_bytes : 0));
         total = off_tiles + (size_t)tiles_pb * tile_stride + table;
     };
+    if (small_batch && writers >= 2 && h->tun_pair_rows != 0) {
+        wsw = 2;
+        lay_out(16, tpb, true);
+        if (total > 96u * 1024u) wsw = 1;
+    }
     lay_out(16, tpb, true);
     if (h->waves_per_block == 0)        // a default never costs the occupancy tables their LDS
         while (tpb > 1 && total > 96u * 1024u) {
@@ -261,6 +269,7 @@ int choose_shape(ccx_handle* h) {
     k.occ_words = s.occ ? (uint32_t)(occ_bytes / 4u) : 0u;
     k.off_table = (uint32_t)(off_tiles + (size_t)tpb * tile_stride);
     k.stage_slots = slots;
+    k.ws_per_writer = (uint32_t)wsw;
     k.wp_magic = (uint32_t)((0x100000000ull + (unsigned long long)(p.width + 3) - 1ull) / (unsigned long long)(p.width + 3));
     k.writer_vmcnt = (uint32_t)s.store_throttle;
     k.writer0_small = (h->tun_writer_roles >= 0 ? h->tun_writer_roles != 0 : (small_batch || small_tiles)) && writers >= 2 ? 1u : 0u;
@@ -1094,6 +1103,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
         {"hand2", &h->tun_hand2, 0, 2},
         {"writer_roles", &h->tun_writer_roles, -1, 1},
         {"max_launch_steps", &h->tun_max_launch_steps, 0, 0x7FFFFFFF},
+        {"pair_rows", &h->tun_pair_rows, -1, 1},
     };
     for (auto& t : table)
         if (strcmp(name, t.name) == 0) {
@@ -1102,7 +1112,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
             *t.slot = value;
             return choose_shape(h);
         }
-    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, hand2, writer_roles, max_launch_steps)", name);
+    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, hand2, writer_roles, max_launch_steps, pair_rows)", name);
 }
 
 int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {

@@ -56,6 +56,7 @@ struct ccx_handle {
     int tun_pace_phase = -1, tun_tile_map = -1;                 // -1 = the library's choice for the launch shape
     int tun_writer_roles = -1;                                  // -1 = by batch size, 0 = writers share everything, 1 = writer 0 small outputs only
     int tun_hand2 = 1;                                          // sim -> writer hand-off: 0 barrier per step, 1 sequence words in unpaced launches, 2 always
+    int tun_pair_rows = -1;                                     // -1 / 1: row writers of small batches may take two steps per iteration (a second staging slot each), 0: never
     int tun_max_launch_steps = 0;                               // > 0: cut rollouts into launches of at most this many steps
     double epsilon = 0.0;                                      // ccx_set_policy_epsilon, as given (the MT19937 stream compares doubles)
     int eps_stream = 0;                                        // CCX_EPS_STREAM_*: where the policies' exploration draws come from

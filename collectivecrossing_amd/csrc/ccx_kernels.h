@@ -118,6 +118,7 @@ struct KParams {
     uint32_t writer0_small;              // 1: writer 0 writes the small outputs only, writers 1.. the observation rows
     uint32_t rng_lo, rng_hi;             // seed of CCX_POLICY_RANDOM and of the epsilon draws (ccx_set_rng_seed)
     uint32_t eps_thr;                    // epsilon * 2^32 of the scripted policies (ccx_set_policy_epsilon), 0 = greedy
+    uint32_t ws_per_writer;              // staging slots (WSlot) per writer wave: 2 where row writers may take two steps per iteration
 #ifdef CCX_LAG_TRACE
     int* lag_trace;                      // diagnostic build: [16 traced tiles][4096 steps] lag behind the schedule, 10-ns ticks
     int lag_every;                       // every lag_every-th tile is traced

@@ -44,4 +44,5 @@ tiles = sh["num_blocks"] * sh["waves_per_block"]
 tot = n * K * tiles
 print(f"E={E} {mode} writers {sh['writers_per_tile']}: {ms / n * 1e3 / K:.4f} us/step | per tile-step: "
       f"writer0 waited {c[8] / tot:.3f} (polls {c[9] / tot:.2f}), writer1 {c[10] / tot:.3f} ({c[11] / tot:.2f}), "
-      f"writer2 {c[12] / tot:.3f} ({c[13] / tot:.2f}); sim lag-waits {c[14] / tot:.4f} (spins {c[15] / tot:.3f})")
+      f"writer2 {c[12] / tot:.3f} ({c[13] / tot:.2f}); sim lag-waits {c[14] / tot:.4f} (spins {c[15] / tot:.3f}); "
+      f"writer1 two-step iterations {c[6] / tot:.3f}")

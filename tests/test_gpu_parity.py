@@ -512,8 +512,8 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
            mode=st.sampled_from(["actions", "actions", "greedy", "waiting", "random"]), compact=st.booleans(),
            writers=st.sampled_from([0, 0, 1, 2, 3, 4]), roles=st.sampled_from([-1, -1, 0, 1]),
            hand2=st.sampled_from([1, 1, 0, 2]), full_tiles=st.booleans(), eps=st.sampled_from([0.0, 0.0, 0.1, 0.5, 1.0]),
-           mt=st.sampled_from([False, False, True]))
-    def run(cfg, seed, E, K, mode, compact, writers, roles, hand2, full_tiles, eps, mt):
+           mt=st.sampled_from([False, False, True]), pair_rows=st.sampled_from([-1, -1, 0]))
+    def run(cfg, seed, E, K, mode, compact, writers, roles, hand2, full_tiles, eps, mt, pair_rows):
         p = lower_config(cfg)
         N = p.num_boarding + p.num_exiting
         rng = np.random.default_rng(seed)
@@ -528,6 +528,7 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
                 env.set_writers(writers)
             env.set_tunable("writer_roles", roles)
             env.set_tunable("hand2", hand2)
+            env.set_tunable("pair_rows", pair_rows)
             if full_tiles and mode in ("actions", "random"):   # (the scripted policies need the LDS occupancy tables)
                 try:
                     env.set_launch_shape(64, 0)

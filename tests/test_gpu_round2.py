@@ -90,7 +90,8 @@ def test_full_size_c3_shuffled_orders_equal_the_oracle(oracle, ccx):
 
 
 @pytest.mark.parametrize("knobs", [{"pace_phase": 0, "tile_map": 0}, {"pace_phase": 1, "tile_map": 1}, {"pace_phase": 2, "tile_map": 4},
-                                   {"pace_phase": 3, "tile_map": 0}, {"pace_phase": 1, "tile_map": 6}, {"hand2": 0}, {"hand2": 2}, {"max_launch_steps": 5}])
+                                   {"pace_phase": 3, "tile_map": 0}, {"pace_phase": 1, "tile_map": 6}, {"hand2": 0}, {"hand2": 2}, {"max_launch_steps": 5},
+                                   {"pair_rows": 0}, {"pair_rows": 1, "hand2": 2}])
 @pytest.mark.parametrize("cfg_name,E,K", [("g1_c1_random", 4096, 70), ("g3_c3_dense_simple_distance", 1500, 20),
                                           ("g1_c1_random", 700, 33)])
 def test_tunables_never_change_results(oracle, ccx, cfg_name, E, K, knobs):
