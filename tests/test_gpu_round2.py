@@ -648,3 +648,19 @@ def test_small_batches_of_tall_grids_keep_the_occupancy_tables(oracle, ccx, E):
         assert env.counters() == ob.counters.as_dict()
     finally:
         env.close()
+
+
+@pytest.mark.parametrize("cfg_name,E", [("g7_n3_small", 700), ("g7_n5_odd", 1000), ("g8_rollout_c1", 300), ("g8_rollout_c1", 1500)])
+@pytest.mark.parametrize("K", [1, 2, 3, 16, 17, 34])
+def test_two_step_row_writer_iterations_equal_the_oracle(oracle, ccx, cfg_name, E, K):
+    """Small batches: row writers own two staging slots and take two env-steps per iteration whenever the sim wave is
+    ahead (tunable pair_rows).  Step counts around the pairing (odd, even, one burst + 1), several agent
+    counts (odd row lengths: the edge-iteration instantiation), shuffled move orders, auto-reset -- against the oracle;
+    and with pairing switched off the same results."""
+    g = Golden(cfg_name)
+    for knobs in ({}, {"pair_rows": 0}, {"hand2": 2}):
+        def setup(env, knobs=knobs):
+            for k, v in knobs.items():
+                env.set_tunable(k, v)
+        c, shape, _, _ = _against_oracle(oracle, ccx, g, E=E, K=K, seed=5 * K + E, setup=setup, order=bool(K & 1))
+        assert shape["writers_per_tile"] >= 2 and c["env_steps"] == E * K
