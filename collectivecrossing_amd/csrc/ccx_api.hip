@@ -231,7 +231,9 @@ int choose_shape(ccx_handle* h) {
         tile_stride = up16(off_occ + (with_occ ? occ_bytes : 0));
         total = off_tiles + (size_t)tiles_pb * tile_stride + table;
     };
-    if (small_batch && writers >= 2 && h->tun_pair_rows != 0) {
+    // (by default only with half tiles, <= 1024 envs of the C2 geometry: +3 % there; at 2048 envs the unpaced write stream is
+    // the limit and two steps' stores back to back cost it 5-7 %: tunable pair_rows = 1 forces it for every small batch)
+    if (small_batch && writers >= 2 && (h->tun_pair_rows == 1 || (h->tun_pair_rows < 0 && half_tiles))) {
         wsw = 2;
         lay_out(16, tpb, true);
         if (total > 96u * 1024u) wsw = 1;

@@ -427,9 +427,10 @@ int ccx_get_pace_start(ccx_handle* h, float* ns_per_env_step, int32_t* source, f
  *                  stream), 0 = a barrier per step always, 2 = the ring always
  *   "max_launch_steps"  > 0: ccx_rollout cuts a rollout into kernel launches of at most this many env-steps (the library
  *                  does so by itself where one launch would exceed 4 GiB per small output stream); 0 = automatic
- *   "pair_rows"    -1 / 1 (default): in small batches (role-split writers, launches that are not paced) every writer gets a
- *                  second staging slot in LDS and a row writer takes TWO env-steps per iteration whenever the simulating
- *                  wavefront is that far ahead; 0 = one step per iteration always */
+ *   "pair_rows"    in small batches (role-split writers, launches that are not paced) every writer can get a second
+ *                  staging slot in LDS and a row writer then takes TWO env-steps per iteration whenever the simulating
+ *                  wavefront is that far ahead: -1 (default) = where it pays (half-tile shapes: up to 128 full tiles),
+ *                  1 = in every small batch, 0 = never */
 int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value);
 /* workgroups of a rollout launch with outputs, and how many of them the device holds at once (a grid
  * larger than that runs in rounds; the pace of a partial last round is scaled accordingly) */

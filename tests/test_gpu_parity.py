@@ -504,11 +504,14 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
     import os
 
     soak = int(os.environ.get("CCX_HYP_EXAMPLES", "0"))     # a one-off soak: CCX_HYP_EXAMPLES=1000 (randomised)
+    # (a soak of the small-batch shapes -- half tiles, role split, two-step row writers -- draws larger batches:
+    #  CCX_HYP_ENVS=257,600,1025,2048,3000)
+    e_list = [int(v) for v in os.environ.get("CCX_HYP_ENVS", "1,5,64,130,257").split(",")]
 
     @settings(max_examples=soak or 50, deadline=None, derandomize=not soak,
               suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much, HealthCheck.function_scoped_fixture])
     @given(cfg=st.one_of(configs(), configs(max_boarding=25, max_exiting=25)), seed=st.integers(0, 2**20),
-           E=st.sampled_from([1, 5, 64, 130, 257]), K=st.integers(1, 48),
+           E=st.sampled_from(e_list), K=st.integers(1, 48),
            mode=st.sampled_from(["actions", "actions", "greedy", "waiting", "random"]), compact=st.booleans(),
            writers=st.sampled_from([0, 0, 1, 2, 3, 4]), roles=st.sampled_from([-1, -1, 0, 1]),
            hand2=st.sampled_from([1, 1, 0, 2]), full_tiles=st.booleans(), eps=st.sampled_from([0.0, 0.0, 0.1, 0.5, 1.0]),

@@ -108,15 +108,15 @@ def test_sgpr_spills_of_the_hot_instantiations(tmp_path):
     pointers, the store iterations' validity is one v_cmp per store instead of ten lane masks, the throttle's threshold
     tests stay inside `if (throttle)`, and the epilogue re-derives its lane predicates: the plain instantiations with
     outputs (the bench line <3,1,1,1,1>, <5,...>, <6,...>) and all instantiations without outputs spill NOTHING; the
-    edge-iteration ones 3-10; the policy / move-order ones 20-67 (C5: v128<6,1,1,1,0> 25, <6,1,2,1,0> 33; round 2: 87 / 103),
-    two to ten of them read inside the sim step loop.  (Making every burst of action loads unconditional freed 14-30 VGPRs and took the C5 pair from 36 / 51 to 25 / 33.)"""
+    edge-iteration ones 3-10; the policy / move-order ones 20-67 (C5: v128<6,1,1,1,0> 27, <6,1,2,1,0> 36; round 2: 87 / 103),
+    two to ten of them read inside the sim step loop.  (Making every burst of action loads unconditional freed 14-30 VGPRs and took the C5 pair from 36 / 51 to 25 / 33; the second copy of the row-writer loop brought it to 27 / 36.)"""
     ks = {k: v for k, v in _kernels(tmp_path).items() if "rollout_kernel" in k}
     occ = {k: v for k, v in ks.items() if re.search(r"ILi\dELb[01]ELi[012]ELb1ELb[01]E", k)}
     plain_out = {k: v[2] for k, v in occ.items() if re.search(r"ILi\dELb[01]ELi[01]ELb1ELb1E", k) and "v128" not in k}
     # (the catch-all LOG=0 instantiation -- agent strides that are no power of two -- may keep a handful, the 64-lane-group one
-    # a single SGPR, written in the prologue and re-read once per writer set-up, outside every loop)
+    # one or two SGPRs in its odd-agent-count form, written in the prologue and re-read once per writer set-up, outside every loop)
     assert len(plain_out) >= 28 and not any(v for k, v in plain_out.items() if "ILi0E" not in k and "ILi6E" not in k), plain_out
-    assert max(plain_out.values()) <= 8 and max(v for k, v in plain_out.items() if "ILi6E" in k) <= 1, plain_out
+    assert max(plain_out.values()) <= 8 and max(v for k, v in plain_out.items() if "ILi6E" in k) <= 2, plain_out
     for tag in ("ILi3ELb1ELi1ELb1ELb1E", "ILi5ELb1ELi1ELb1ELb1E"):       # (the bench line's kernel; 32-lane groups: C3)
         assert [v for k, v in plain_out.items() if tag in k] == [0], tag
     edge = {k: v[2] for k, v in occ.items() if re.search(r"ILi\dELb[01]ELi2ELb1ELb1E", k) and "v128" not in k}
@@ -124,4 +124,4 @@ def test_sgpr_spills_of_the_hot_instantiations(tmp_path):
     rest = {k: v[2] for k, v in occ.items() if "v128" in k}
     assert max(rest.values()) <= 72, {k: v for k, v in rest.items() if v > 72}
     c5 = {k: v[2] for k, v in occ.items() if re.search(r"v128ILi6ELb1ELi[12]ELb1ELb0E", k)}
-    assert len(c5) == 2 and max(c5.values()) <= 40, c5
+    assert len(c5) == 2 and max(c5.values()) <= 44, c5
