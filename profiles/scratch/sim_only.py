@@ -37,6 +37,11 @@ def timed(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3 / K
 
 
+from collectivecrossing_amd.batched import RolloutResult  # noqa: E402
+only_ef = RolloutResult(None, None, None, small.env_flags, None)        # the hand-off with (almost) nothing behind it
+only_rew = RolloutResult(None, small.reward, None, None, None)
+print(f"E={E}: env flags only {timed(lambda: env.rollout(acts, auto_reset=True, out=only_ef)):.4f}  "
+      f"rewards only {timed(lambda: env.rollout(acts, auto_reset=True, out=only_rew)):.4f} us per env-step", flush=True)
 print(f"E={E} {' '.join(sys.argv[2:])} lib={os.environ.get('CCX_DIAG_LIB', 'shipped')[-16:]}: "
       f"sim only {timed(lambda: env.rollout(acts, auto_reset=True, want_traj=False)):.4f}  "
       f"rewards+flags {timed(lambda: env.rollout(acts, auto_reset=True, out=small)):.4f}  "
