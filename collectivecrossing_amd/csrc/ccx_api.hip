@@ -291,6 +291,12 @@ int choose_shape(ccx_handle* h) {
     const bool can_saturate = s.step_bytes / 7000.0 >= 450.0;
     k.pace_state = (h->step_pace_ns == -1 || (h->step_pace_ns == 0 && !can_saturate)) ? nullptr : h->pace_state;
     k.pace_adapt = (h->step_pace_ns == 0) ? 1u : 0u;
+    {   // how many steps make a launch worth pacing (~12 us) / long enough to judge its lateness (~50 us), at the assumed rate
+        const double step_ns = s.step_bytes / 6800.0;
+        const double a = std::ceil(50000.0 / (step_ns > 1.0 ? step_ns : 1.0));
+        k.adapt_min_k = (uint32_t)(a < 4.0 ? 4.0 : a > 64.0 ? 64.0 : a);
+        k.pace_min_k = k.adapt_min_k / 4u < 2u ? 2u : k.adapt_min_k / 4u;
+    }
     k.resident_blocks = (uint32_t)s.resident_blocks;
 
     // observation address table of this shape (ccx_kernels.h: obs_unit_addr).  Shape changes are rare and
@@ -466,15 +472,15 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
         // Never inside a stream capture: the memsets would become graph nodes and every replay would re-zero the
         // controller's state, and the calibration must synchronise.  A launch that needs the (re)start is
         // refused while capturing; run one eager launch of the shape first.
-        if (capturing && ccx::launch_is_paced(h->kp.pace_state != nullptr, writes_obs, K))
+        if (capturing && ccx::launch_is_paced(h->kp.pace_state != nullptr, writes_obs, K, h->kp.pace_min_k))
             return fail(CCX_EINVAL, "the pace controller of this handle must be (re)started (new handle, launch shape or "
                         "setting): run one eager rollout of this shape before capturing it into a graph");
-        const bool paced_launch = ccx::launch_is_paced(h->kp.pace_state != nullptr, writes_obs, K);
+        const bool paced_launch = ccx::launch_is_paced(h->kp.pace_state != nullptr, writes_obs, K, h->kp.pace_min_k);
         if (!h->kp.pace_state) {
             h->pace_dirty = false;              // rollouts of this shape are not paced at all
         } else if (!capturing && paced_launch) {   // (launches that are not paced never look at the controller: nothing to do yet)
             const bool adaptive_launch =
-                ccx::launch_is_adaptive(h->kp.pace_state != nullptr, h->kp.pace_adapt != 0u, writes_obs, K);
+                ccx::launch_is_adaptive(h->kp.pace_state != nullptr, h->kp.pace_adapt != 0u, writes_obs, K, h->kp.pace_min_k, h->kp.adapt_min_k);
             const bool wants_calibration = h->kp.pace_adapt != 0u && h->pace_calibrate && h->pace_start_ns <= 0.0f;
             if (adaptive_launch && wants_calibration) {
                 const size_t obs_bytes = (size_t)K * (size_t)h->E * h->N * (size_t)(6 + 4 * h->N) * sizeof(float);
@@ -507,7 +513,7 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     ccx::KParams kp = h->kp;
     // launches the kernel will not pace hand steps to the writer waves through sequence words (ccx_kernels.h: one
     // definition of the launch modes for the host and the kernel)
-    kp.hand_flags = ccx::launch_uses_flags(kp.pace_state != nullptr, writes_obs, K, h->tun_hand2) ? 1u : 0u;
+    kp.hand_flags = ccx::launch_uses_flags(kp.pace_state != nullptr, writes_obs, K, kp.pace_min_k, h->tun_hand2) ? 1u : 0u;
 #ifdef CCX_LAG_TRACE
     {
         static int* lag_buf = nullptr;
@@ -519,7 +525,7 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
         g_lag_buf = lag_buf;
     }
 #endif
-    const bool adaptive = ccx::launch_is_adaptive(kp.pace_state != nullptr, kp.pace_adapt != 0u, writes_obs, K);
+    const bool adaptive = ccx::launch_is_adaptive(kp.pace_state != nullptr, kp.pace_adapt != 0u, writes_obs, K, kp.pace_min_k, kp.adapt_min_k);
     if (adaptive && capturing) kp.pace_adapt = 0u;
     int rc = begin_timed(h);
     if (rc) return rc;

@@ -69,14 +69,18 @@ constexpr uint32_t kCellInTram = 0x20u, kCellAtDoor = 0x40u;
 // handle paces its shape, it writes observation rows and is long enough to be worth the clock reads; the pace controller
 // ADAPTS (votes, slot flip on the host) only in paced launches of at least 64 steps; launches that are not paced hand
 // steps from the sim wave to the writer waves through sequence words instead of a barrier per step (tunable "hand2").
-__host__ __device__ inline bool launch_is_paced(bool handle_paces, bool writes_obs, int K) {
-    return handle_paces && writes_obs && K >= 16;
+// The two step counts are per launch SHAPE (KParams::pace_min_k / adapt_min_k, set by the host: a launch must last ~12 us
+// to be worth pacing and ~50 us for its lateness to be judged -- 16 / 64 steps of C2's 0.78-us steps, 2 / 5 of C3's 10-us
+// ones; rounds 1-2 used 16 / 64 for every shape, which left short rollouts of large tiles at their start pace).
+__host__ __device__ inline bool launch_is_paced(bool handle_paces, bool writes_obs, int K, uint32_t pace_min_k) {
+    return handle_paces && writes_obs && K >= (int)pace_min_k;
 }
-__host__ __device__ inline bool launch_is_adaptive(bool handle_paces, bool handle_adapts, bool writes_obs, int K) {
-    return launch_is_paced(handle_paces, writes_obs, K) && handle_adapts && K >= 64;
+__host__ __device__ inline bool launch_is_adaptive(bool handle_paces, bool handle_adapts, bool writes_obs, int K,
+                                                   uint32_t pace_min_k, uint32_t adapt_min_k) {
+    return launch_is_paced(handle_paces, writes_obs, K, pace_min_k) && handle_adapts && K >= (int)adapt_min_k;
 }
-__host__ __device__ inline bool launch_uses_flags(bool handle_paces, bool writes_obs, int K, int tunable) {
-    return tunable >= 2 || (tunable == 1 && !launch_is_paced(handle_paces, writes_obs, K));   // 0 = never, 1 = unpaced launches, 2 = always
+__host__ __device__ inline bool launch_uses_flags(bool handle_paces, bool writes_obs, int K, uint32_t pace_min_k, int tunable) {
+    return tunable >= 2 || (tunable == 1 && !launch_is_paced(handle_paces, writes_obs, K, pace_min_k));   // 0 = never, 1 = unpaced launches, 2 = always
 }
 enum : uint32_t { CCX_K_EF_ALL_TERM = 1u, CCX_K_EF_ALL_TRUNC = 2u, CCX_K_EF_RESET = 4u };
 
@@ -119,6 +123,7 @@ struct KParams {
     uint32_t rng_lo, rng_hi;             // seed of CCX_POLICY_RANDOM and of the epsilon draws (ccx_set_rng_seed)
     uint32_t eps_thr;                    // epsilon * 2^32 of the scripted policies (ccx_set_policy_epsilon), 0 = greedy
     uint32_t ws_per_writer;              // staging slots (WSlot) per writer wave: 2 where row writers may take two steps per iteration
+    uint32_t pace_min_k, adapt_min_k;    // a launch is paced from pace_min_k steps on, the controller adapts from adapt_min_k on
 #ifdef CCX_LAG_TRACE
     int* lag_trace;                      // diagnostic build: [16 traced tiles][4096 steps] lag behind the schedule, 10-ns ticks
     int lag_every;                       // every lag_every-th tile is traced

@@ -378,8 +378,9 @@ int ccx_set_store_throttle(ccx_handle* h, int32_t max_stores_in_flight);
  * the HBM drain rate instead of bursts that oversubscribe the write queues.
  *   0  = adaptive (default): starts from the write rate measured in-process at the first long rollout
  *        (ccx_set_pace_calibration; an assumed 6.8 TB/s without it) and is retuned by the kernel after every
- *        launch of >= 64 steps (late => slower, on time => 0.4 % faster, a collapse of the drain rate =>
- *        +3 % and a decaying floor); batches too small to fill the drain rate are not paced at all
+ *        launch that lasts ~50 us or more (64 steps of the 4096 x 8 shape, 5 of a 4096 x 32 one; a launch
+ *        shorter than ~12 us is not paced at all: late => slower, on time => 0.4 % faster, a collapse of the drain
+ *        rate => +3 % and a decaying floor); batches too small to fill the drain rate are not paced at all
  *   -1 = off;   > 0 = fixed pace in nanoseconds per env-step.
  * ccx_get_step_pace returns the pace in effect (synchronises).  Results never depend on it. */
 int ccx_set_step_pace(ccx_handle* h, int32_t ns_per_env_step);
@@ -395,7 +396,7 @@ int ccx_get_pace_state(ccx_handle* h, float* out6);
  * controller. */
 int ccx_set_step_pace_start(ccx_handle* h, float ns_per_env_step);
 /* Start-up calibration (default on; CCX_PACE_CALIBRATION=0 in the environment turns it off for new handles).  The first
- * adaptive paced rollout of a handle / launch shape -- one that writes observations for >= 64 steps -- first streams
+ * adaptive paced rollout of a handle / launch shape -- one that writes observations for ~50 us or more -- first streams
  * filler into the caller's own observation buffer (which that rollout overwrites anyway) for ~2.5 ms with the writer
  * wavefronts' store type, takes the best pass as a lower bound of the drain rate of this box and starts the controller
  * 5 % above it (it descends further by itself until a launch comes in late).  One stream synchronisation; never inside a stream capture (a rollout that would have to restart

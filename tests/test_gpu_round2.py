@@ -664,3 +664,31 @@ def test_two_step_row_writer_iterations_equal_the_oracle(oracle, ccx, cfg_name, 
                 env.set_tunable(k, v)
         c, shape, _, _ = _against_oracle(oracle, ccx, g, E=E, K=K, seed=5 * K + E, setup=setup, order=bool(K & 1))
         assert shape["writers_per_tile"] >= 2 and c["env_steps"] == E * K
+
+
+def test_short_rollouts_of_large_tiles_are_adaptive_too(oracle, ccx):
+    """The step counts from which a launch is paced / the controller adapts are per launch shape (~12 us / ~50 us of
+    planned duration): 16 / 64 steps of the 4096 x 8 shape, 2 / 5 of the 4096 x 32 one.  Rounds 1-2 used 16 / 64 for every
+    shape, so 20-step rollouts of C3 never calibrated and stayed at the assumed start pace (0.81 instead of 0.87 of the
+    peak).  Here: C3 at 20 steps per launch calibrates at its first launch, its pace moves over the next ones, and the
+    trajectory is the oracle's; the C2 shape keeps 16 / 64 (the boundary sweep above)."""
+    import torch
+    g = Golden("g3_c3_dense_simple_distance")
+    E, K = 4096, 20
+    env = ccx(g.config, E)
+    env.make_reset_pool(0, 512)
+    env.reset_from_pool()
+    acts = torch.randint(0, 5, (K, E, g.N), dtype=torch.uint8, device=env.device)
+    traj = env.alloc_rollout(K)
+    assert env.pace_start()["source"] == "assumed"
+    env.rollout(acts, auto_reset=True, out=traj)
+    env.synchronize()
+    ps = env.pace_start()
+    assert ps["source"] == "calibration" and 3000 < ps["probe_GBs"] < 9000, ps
+    paces = []
+    for _ in range(12):
+        env.rollout(acts, auto_reset=True, out=traj)
+        paces.append(env.pace_state()["next_pace_ns"])
+    assert len({round(p, 1) for p in paces}) > 3 and min(paces) < ps["ns"], (ps, paces)     # the controller descends
+    env.close()
+    _against_oracle(oracle, ccx, g, E=1500, K=9, seed=77)             # (9 steps: adaptive for this shape) == the oracle
