@@ -361,6 +361,20 @@ def secondary_figures(torch, env, actions, chunk: int) -> dict:
     out["no_obs"] = {"env_steps_per_sec": chunk * E / (ms * 1e-3), "us_per_env_step": ms * 1e3 / chunk,
                      "what": f"ccx_rollout, {chunk} steps per launch, rewards + flag bytes only"}
     del small
+    # the same rollout with the compact observation output ([E][N][4] rows, include/ccx.h: CCX_OBS_COMPACT) instead of the
+    # DefaultObservation rows: what a consumer on the GPU would ask for; bound by the sim wave, not by memory
+    comp = env.alloc_rollout(chunk, want_obs=False, want_compact=True)
+    for _ in range(3):
+        env.rollout(actions[:chunk], auto_reset=True, out=comp)
+    e0.record()
+    for _ in range(reps):
+        env.rollout(actions[:chunk], auto_reset=True, out=comp)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    out["compact_obs"] = {"env_steps_per_sec": chunk * E / (ms * 1e-3), "us_per_env_step": ms * 1e3 / chunk,
+                          "what": f"ccx_rollout, {chunk} steps per launch, rewards + flag bytes + compact observation rows"}
+    del comp
     for _ in range(20):
         env.step(actions[0])
     reps = 200

@@ -64,6 +64,7 @@ def test_bench_line_has_the_contract_fields_and_adds_up():
     sec = d["secondary"]
     assert 0.1 < sec["no_obs"]["us_per_env_step"] < 5 and 1 < sec["step_k1"]["us_per_step"] < 100
     assert 1 < sec["step_k1_graph"]["us_per_step"] < 100          # (the same launches without the host in the loop)
+    assert sec["no_obs"]["us_per_env_step"] * 0.8 < sec["compact_obs"]["us_per_env_step"] < 5
 
 
 def test_bench_with_a_pace_cache_says_so(tmp_path):
