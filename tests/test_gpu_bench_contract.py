@@ -58,6 +58,7 @@ def test_bench_line_has_the_contract_fields_and_adds_up():
     assert c["pace_start_source"] == "calibration" and c["pace_start_ns"] > 0 and 3000 < c["pace_probe_GBs"] < 9000
     assert cold["pace_start_source"] == "calibration" and d["cold_unseeded"]["value"] == cold["value"]
     assert "steady state" in d["value_protocol"]
+    assert d["retimed"] is None or d["retimed"]["first_wall_over_kernel_time"] > 1.15      # (only after a host stall)
     assert r["frac_wall"] == pytest.approx(r["bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9 / 8000.0, rel=1e-9)
     assert r["frac_wall"] <= r["frac"] * 1.001 and cold["frac_wall"] <= cold["frac"] * 1.001
     assert d["rccl_ranks"] == 0 and d["collective_backend"] is None and d["per_rank_env_steps_per_sec"][0] >= d["value"] * 0.999
