@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ISA inspection helper for the rollout kernels (CPU-only).  usage:
-  isa.py build [GLOG]         compile ccx_kernels.hip (one lane-group size: seconds) with -save-temps into /tmp/asm
+  isa.py build [GLOG]         compile ccx_rollout_g.hip (one lane-group size, default 3: seconds) with -save-temps into /tmp/asm
   isa.py res [pattern]        VGPR / SGPR / spills / scratch per kernel from the last build
   isa.py loop <mangled-substring> [out.s]   the sim step loop (from the occupancy atomics' block to its back edge)"""
 import re
@@ -16,14 +16,15 @@ FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno
 
 def build(glog):
     TMP.mkdir(exist_ok=True)
-    defs = [f"-DCCX_ONLY_GLOG={glog}"] if glog is not None else []
-    tag = f"g{glog}" if glog is not None else "all"
+    glog = 3 if glog is None else glog
+    defs = [f"-DCCX_GLOG={glog}"]
+    tag = f"g{glog}"
     r = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *defs, "-save-temps=obj", "-Rpass-analysis=kernel-resource-usage",
-                        "-c", "ccx_kernels.hip", "-o", str(TMP / f"{tag}.o")], cwd=SRC, capture_output=True, text=True)
+                        "-c", "ccx_rollout_g.hip", "-o", str(TMP / f"{tag}.o")], cwd=SRC, capture_output=True, text=True)
     (TMP / f"{tag}_res.txt").write_text(r.stderr)
     errs = [ln for ln in r.stderr.splitlines() if not ln.startswith("remark")]
     print("\n".join(errs[:60]))
-    src = TMP / "ccx_kernels-hip-amdgcn-amd-amdhsa-gfx950.s"
+    src = TMP / "ccx_rollout_g-hip-amdgcn-amd-amdhsa-gfx950.s"
     if src.exists():
         src.replace(TMP / f"{tag}.s")
     (TMP / "last").write_text(tag)
