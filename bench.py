@@ -112,9 +112,10 @@ def write_bandwidth_probe(torch, dev, buf) -> float:
     return nbytes / (best * 1e-3) / 1e9
 
 
-def cpu_baseline(config, n_agents: int, seconds_target: float = 12.0) -> dict:
+def cpu_baseline(config, n_agents: int, seconds_target: float = 7.0) -> dict:
     """The CPU oracle (a C port of the reference's sequential algorithm) on the host cores, same
-    workload (full trajectory outputs), bounded sample."""
+    workload (full trajectory outputs), bounded sample: ~2.5 s on one thread, then ~3.5 s on one thread per
+    schedulable core (os.cpu_count() workers; both the box's count and the threads used are stated)."""
     import numpy as np
 
     from collectivecrossing_amd.params import lower_config
@@ -123,8 +124,24 @@ def cpu_baseline(config, n_agents: int, seconds_target: float = 12.0) -> dict:
 
     params = lower_config(config)
     pool = build_reset_pool(config, 0, 128)
-    cores = min(os.cpu_count() or 1, 16)
-    E_t, K = 64, 500  # per thread: 64 envs x 500 steps, trajectory 39 MB
+    box_cores = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = box_cores
+    quota = None                                  # a container's CPU share (cgroup v2 cpu.max / v1 cfs quota), in cores
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            quota = q / float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text()) if q > 0 else None
+        except Exception:
+            pass
+    # one thread per core this process can really run on: os.cpu_count() unless an affinity mask or a cgroup quota says less
+    cores = max(1, min(box_cores, affinity, int(quota + 0.999) if quota else box_cores, 128))
+    E_t, K = 64, 250  # per thread: 64 envs x 250 steps, trajectory 20 MB
 
     def make(seed):
         b = ref.OracleBatch(params, E_t)
@@ -138,14 +155,14 @@ def cpu_baseline(config, n_agents: int, seconds_target: float = 12.0) -> dict:
     b.rollout(acts[:50], auto_reset=True)  # warm-up
     t0 = time.perf_counter()
     reps1 = 0
-    while time.perf_counter() - t0 < seconds_target * 0.4:
+    while time.perf_counter() - t0 < seconds_target * 0.35:
         b.rollout(acts, auto_reset=True)
         reps1 += 1
     dt1 = time.perf_counter() - t0
     single = reps1 * E_t * K / dt1
     # all cores: one thread per core, each on its own envs (ctypes releases the GIL)
-    workers = [make(100 + i) for i in range(cores)]
-    reps = max(1, int(reps1 * 1.2))
+    workers = [(b, acts)] + [make(100 + i) for i in range(1, cores)]
+    reps = max(1, int(reps1 * 1.3))
 
     def run(w):
         for _ in range(reps):
@@ -160,6 +177,7 @@ def cpu_baseline(config, n_agents: int, seconds_target: float = 12.0) -> dict:
     dtm = time.perf_counter() - t0
     multi = cores * reps * E_t * K / dtm
     return {"value": multi, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "cores_of_the_box": box_cores, "cores_in_affinity_mask": affinity, "cgroup_cpu_quota": quota, "threads_used": cores,
             "single_core_value": single,
             "sample": (f"oracle/ccx_oracle.c ccxo_rollout, same config/outputs (full trajectory), "
                        f"{cores} threads x {reps} x ({E_t} envs x {K} steps) in {dtm:.1f}s; "
@@ -419,6 +437,168 @@ def secondary_figures(torch, env, actions, chunk: int) -> dict:
     return out
 
 
+def measure_workload(torch, dev, name: str, envs: int, chunk: int, policy: str, settle: int = 30, timed: int = 10) -> dict:
+    """One BASELINE workload / batch size measured like the headline, in this process, on a handle of its own: `settle`
+    untimed launches (the first adaptive one calibrates the pace controller in-process), then `timed` launches between
+    synchronize pairs with a HIP-event pair around each: frac = algorithmic bytes / mean kernel time / 8 TB/s, frac_wall the
+    same bytes over the wall clock of the window.  Full trajectory outputs, auto-reset from 1024 seeded placements."""
+    import numpy as np
+
+    from collectivecrossing_amd.batched import BatchedCollectiveCrossing
+    config, e_default = workload_config(name)
+    E = envs or e_default
+    env = BatchedCollectiveCrossing(config, E, device=dev)
+    try:
+        N = env.num_agents
+        env.make_reset_pool(0, 1024, on_device=True)
+        env.reset_from_pool()
+        actions = None
+        if policy == "random":
+            gen = torch.Generator(device=dev).manual_seed(4321)
+            actions = torch.randint(0, 5, (chunk, E, N), dtype=torch.uint8, device=dev, generator=gen)
+        traj = env.alloc_rollout(chunk)
+
+        def launch():
+            if policy == "greedy":
+                env.rollout_greedy(chunk, auto_reset=True, out=traj, want_actions=False)
+            else:
+                env.rollout(actions, auto_reset=True, out=traj)
+
+        for _ in range(settle):
+            launch()
+        torch.cuda.synchronize(dev)
+        events = []
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch()
+            e1.record()
+            events.append((e0, e1))
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        ms = [a.elapsed_time(b) for a, b in events]
+        launch_bytes = rollout_bytes_per_agent_step(N) * chunk * E * N
+        kern = float(np.mean(ms))
+        return {"workload": name, "envs": E, "agents": N, "policy": policy, "steps_per_launch": chunk,
+                "settle_launches": settle, "timed_launches": timed,
+                "env_steps_per_sec": timed * chunk * E / wall, "kernel_ms_per_launch": kern,
+                "kernel_ms_min_median_max": [float(np.min(ms)), float(np.median(ms)), float(np.max(ms))],
+                "bytes_per_launch": launch_bytes,
+                "frac": launch_bytes / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "frac_wall": launch_bytes * timed / wall / 1e9 / HBM_PEAK_GBS,
+                "launch_shape": env.launch_shape(), "step_pace_ns": env.step_pace_ns()}
+    finally:
+        env.close()
+        torch.cuda.empty_cache()
+
+
+# (workload, envs per GPU or 0 = the workload's own, env-steps per launch, policy): BASELINE configs[2] and [4] (both agent
+# counts), and the C2 geometry from 1024 to 65 536 envs (small batches, several rounds of workgroups) -- VERDICT r3 item 2
+SECONDARY_WORKLOADS = [("c3", 0, 500, "random"), ("c5_50", 0, 500, "greedy"), ("c5_64", 0, 500, "greedy"),
+                       ("c2", 1024, 500, "random"), ("c2", 2048, 500, "random"), ("c2", 16384, 64, "random"),
+                       ("c2", 32768, 64, "random"), ("c2", 65536, 24, "random")]
+
+
+def secondary_workloads(torch, dev) -> list:
+    out = []
+    for name, envs, chunk, policy in SECONDARY_WORKLOADS:
+        try:
+            out.append(measure_workload(torch, dev, name, envs, chunk, policy))
+        except Exception as exc:      # (a secondary figure must never cost the bench line)
+            out.append({"workload": name, "envs": envs, "error": repr(exc)})
+    return out
+
+
+def sustained_window(torch, env, actions, chunk: int, traj, seconds: float = 2.5, bucket_s: float = 0.25) -> dict:
+    """The headline's launches issued continuously for `seconds` (nothing showed the pace controller / the HBM
+    write stream holding over more than 0.1 s): HIP-event pair around every launch, the launches grouped into buckets of
+    `bucket_s` by their position in the stream; the fraction of the peak by the WALL clock of the whole window."""
+    import numpy as np
+    dev = env.device
+    E, N = env.num_envs, env.num_agents
+    n_buf = max(1, actions.shape[0] // chunk)
+    launch_bytes = rollout_bytes_per_agent_step(N) * chunk * E * N
+    torch.cuda.synchronize(dev)
+    events = []
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0 = (k % n_buf) * chunk
+        e0.record()
+        env.rollout(actions[a0:a0 + chunk], auto_reset=True, out=traj)
+        e1.record()
+        events.append((e0, e1))
+        k += 1
+        if k % 64 == 0:
+            # (the host must not run unboundedly ahead of the device: wait for the launch issued 64 launches ago)
+            events[k - 64][1].synchronize()
+            if time.perf_counter() - t0 >= seconds:
+                break
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    ms = np.array([a.elapsed_time(b) for a, b in events])
+    starts = np.array([events[0][0].elapsed_time(a) for a, _ in events]) * 1e-3     # seconds since the first launch
+    buckets = []
+    nb = int(np.ceil((starts[-1] + 1e-9) / bucket_s))
+    for b in range(nb):
+        sel = ms[(starts >= b * bucket_s) & (starts < (b + 1) * bucket_s)]
+        if sel.size:
+            buckets.append({"t_s": round(b * bucket_s, 3), "launches": int(sel.size), "ms_min": float(sel.min()),
+                            "ms_median": float(np.median(sel)), "ms_max": float(sel.max()),
+                            "frac_median": launch_bytes / (float(np.median(sel)) * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    return {"what": f"{k} back-to-back {chunk}-step launches of the headline workload, issued continuously",
+            "seconds": wall, "launches": k, "env_steps_per_sec": k * chunk * E / wall,
+            "frac_wall": launch_bytes * k / wall / 1e9 / HBM_PEAK_GBS,
+            "frac_kernel_mean": launch_bytes / (float(ms.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "kernel_ms_min_median_max": [float(ms.min()), float(np.median(ms)), float(ms.max())],
+            "launches_over_1p05_median": int((ms > 1.05 * np.median(ms)).sum()),
+            "buckets": buckets}
+
+
+def short_launches(torch, env, actions) -> dict:
+    """Launches of K = 1 ... 64 env-steps (policy-in-the-loop callers: the reference's literal step() is K = 1), full outputs,
+    each K captured into a HIP graph of `n` launches and replayed: us per launch on the device and the fraction of the HBM
+    peak its algorithmic bytes reach."""
+    dev = env.device
+    E, N = env.num_envs, env.num_agents
+    out = {}
+    side = torch.cuda.Stream(device=dev)
+    env.use_stream(side)
+    try:
+        with torch.cuda.stream(side):
+            for K in (1, 2, 4, 8, 16, 32, 64):
+                n = max(4, min(50, actions.shape[0] // K))
+                traj = env.alloc_rollout(K)
+                for _ in range(3):
+                    env.rollout(actions[:K], auto_reset=True, out=traj)
+                side.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    for k in range(n):
+                        env.rollout(actions[k * K:(k + 1) * K], auto_reset=True, out=traj)
+                graph.replay()
+                side.synchronize()
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record(side)
+                for _ in range(10):
+                    graph.replay()
+                g1.record(side)
+                side.synchronize()
+                us = g0.elapsed_time(g1) * 1e3 / (10 * n)
+                nbytes = rollout_bytes_per_agent_step(N) * K * E * N
+                out[f"k{K}"] = {"us_per_launch": us, "us_per_env_step": us / K, "env_steps_per_sec": K * E / (us * 1e-6),
+                                "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                del graph, traj
+    except Exception as exc:
+        out["error"] = repr(exc)
+    finally:
+        env.use_stream(torch.cuda.current_stream(dev))
+    out["what"] = "ccx_rollout launches of K env-steps with full outputs, captured into HIP graphs and replayed"
+    return out
+
+
 def run_rank(args) -> int:
     import numpy as np
     import torch
@@ -475,6 +655,7 @@ def run_rank(args) -> int:
     trajs = [env.alloc_rollout(chunk, want_obs=not args.no_obs, want_compact=args.compact_obs) for _ in range(max(1, args.buffers))]
     traj = trajs[0]
     views = [t if not args.only_obs else type(t)(t.obs, None, None, None, t.obs_compact) for t in trajs]
+    n_views = len(views)
     launched = 0
 
     def run(nlaunches, events=None):
@@ -553,8 +734,21 @@ def run_rank(args) -> int:
 
     probe = write_bandwidth_probe(torch, dev, traj.obs if traj.obs is not None else traj.reward) if rank == 0 else None
     secondary = None
+    cpu_line = None
     if rank == 0 and world == 1 and not args.no_secondary and args.policy == "random" and not args.no_obs:
         secondary = secondary_figures(torch, env, actions, chunk)
+        if args.workload == "c2" and not args.envs_per_gpu and not os.environ.get("CCX_DIAG_LIB"):
+            secondary["short_launches"] = short_launches(torch, env, actions)
+            secondary["sustained"] = sustained_window(torch, env, actions, chunk, traj)
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and args.workload == "c2" and args.policy == "random":
+        # (between the GPU legs: the driver's activity sampler sees a busy GPU before AND after these ~7 s)
+        cpu_line = cpu_baseline(config, N)
+    if secondary is not None and args.workload == "c2" and not args.envs_per_gpu and not os.environ.get("CCX_DIAG_LIB"):
+        trajs.clear()
+        views.clear()
+        traj = None
+        torch.cuda.empty_cache()
+        secondary["workloads"] = secondary_workloads(torch, dev)
     if rank == 0:
         assert os.environ.get("CCX_DIAG_LIB") or counters["env_steps"] == args.steps * chunk * total, counters
         props = torch.cuda.get_device_properties(dev)
@@ -602,7 +796,7 @@ def run_rank(args) -> int:
                        "trajectory_buffer": ("every launch rewrites ONE set of [steps, envs, agents] output buffers (a fixed RL rollout "
                                              "buffer, %.2f GB here); launches that cycle through > 3 GB of output memory sustain "
                                              "0.86-0.88 of the peak instead of 0.90 (DESIGN.md 3.6)") % (chunk * E * N * rollout_bytes_per_agent_step(N) / 1e9),
-                       "trajectory_buffers": len(views),
+                       "trajectory_buffers": n_views,
                        "env_steps_per_step": chunk, "steps_per_launch": chunk,
                        "ms_per_env_step": elapsed * 1e3 / (args.steps * chunk),
                        "settle_launches": settle,
@@ -628,8 +822,8 @@ def run_rank(args) -> int:
         }
         if secondary:
             line["secondary"] = secondary
-        if not args.no_cpu_baseline and world == 1 and args.workload == "c2" and args.policy == "random":
-            line["cpu_baseline"] = cpu_baseline(config, N)
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
         elif world > 1:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # ccx_status
 OK, EINVAL, ENOMEM, EHIP, ENODEVICE = 0, -1, -2, -3, -4
@@ -134,6 +134,7 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_set_tunable": (C.c_int, [_H, C.c_char_p, C.c_int32]),
     "ccx_get_residency": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccx_get_writer_shape": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ccx_get_step_shape": (C.c_int, [_H] + [C.POINTER(C.c_int32)] * 5),
     "ccx_get_launch_shape": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccx_host_device_pointer": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -522,6 +522,13 @@ class BatchedCollectiveCrossing:
                          "writers_per_tile", "store_throttle", "resident_blocks"),
                         (int(x.value) for x in v + w + r[:1])))
 
+    def step_shape(self) -> dict[str, int]:
+        """Launch shape of the short-launch kernel (``ccx_get_step_shape``): ``ok`` = 1 when ``step`` / rollouts of at most
+        16 steps without a move order run the short-launch kernel (csrc/ccx_step.hip: a sim wave + ``row_waves`` row waves per tile)."""
+        v = [C.c_int32() for _ in range(5)]
+        check(self._lib.ccx_get_step_shape(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("ok", "lanes_per_wave", "row_waves", "num_blocks", "lds_bytes"), (int(x.value) for x in v)))
+
     def use_stream(self, stream: "torch.cuda.Stream | None" = None) -> None:
         """Launch on ``stream`` (default: torch's current stream of the device) from now on."""
         self._stream = stream if stream is not None else torch.cuda.current_stream(self.device)

@@ -314,6 +314,7 @@ int choose_shape(ccx_handle* h) {
     h->pace_start_source = h->step_pace_ns > 0 ? CCX_PACE_START_FIXED
                            : h->pace_start_ns > 0.0f ? CCX_PACE_START_CALLER : CCX_PACE_START_ASSUMED;
     h->pace_dirty = true;
+    h->pace_needs_calibration = false;
     k.r_dest = p.boarding_destination_reward; k.r_door = p.tram_door_reward;
     k.r_area = p.tram_area_reward; k.r_f = p.distance_penalty_factor;
     k.r_nogoal = p.no_goal_reward; k.r_pen = p.step_penalty;
@@ -345,6 +346,26 @@ int choose_shape(ccx_handle* h) {
         while ((1 << (auto_map - 1)) < g) ++auto_map;
     }
     k.tile_map = (uint32_t)(h->tun_tile_map >= 0 ? h->tun_tile_map : auto_map);
+
+    // Short launches (<= 16 steps, ccx_step.hip): a workgroup = one tile = a sim wave + row waves, as many tiles as the
+    // batch allows up to ~4 per CU (a short launch is bound by latency, not by issue), never more envs per wave than the
+    // rollout shape (the observation address table of a smaller tile is a prefix of the rollout's).  Row waves: enough that
+    // one handles <= ~6 store iterations per step (small tiles) or ~10 (large ones), at most 7.  Grids whose tables exceed the LDS keep the rollout kernel.
+    {
+        ccx::StepShape& ss = h->step_shape;
+        int sew = ew;
+        if (h->tun_step_lanes > 0) sew = std::max(1, std::min(ew, h->tun_step_lanes / G));
+        else while (sew > 1 && (h->E + sew - 1) / sew < 4 * h->num_cus) sew >>= 1;
+        ss.glog = glog;
+        ss.envs_per_wave = sew;
+        ss.lds_bytes = ccx::step_lds_bytes(glog, sew, h->N, (int)cells);
+        const int sunits = sew * h->N * (3 + 2 * h->N);
+        const int sits = ((h->N % 2 == 0 ? sunits / 2 : sunits) + 63) / 64;
+        ss.row_waves = h->tun_step_rows > 0 ? h->tun_step_rows
+                       : sits <= 6 ? 1 : sits <= 12 ? 2 : sits <= 33 ? 3 : std::min(7, (sits + 9) / 10);
+        ss.num_blocks = (h->E + sew - 1) / sew;
+        ss.ok = (s.occ && ss.lds_bytes <= 96u * 1024u) ? 1 : 0;
+    }
     return CCX_OK;
 }
 
@@ -398,7 +419,10 @@ int calibrate_pace(ccx_handle* h, float* obs, size_t obs_bytes) {
     if (bytes < ((size_t)16 << 20)) return CCX_OK;            // too small a buffer to say anything about a stream
     hipEvent_t e0 = nullptr, e1 = nullptr;
     CCX_HIP(hipEventCreate(&e0));
-    CCX_HIP(hipEventCreate(&e1));
+    if (hipError_t ee = hipEventCreate(&e1); ee != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return fail(CCX_EHIP, "hipEventCreate failed: %s", hipGetErrorString(ee));
+    }
     double best_gbs = 0.0, spent_ms = 0.0;
     int rc = CCX_OK;
     for (int pass = 0; pass < 24 && spent_ms < 2.5 && rc == CCX_OK; ++pass) {
@@ -436,6 +460,16 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
         const unsigned long long fit = 0xFFFFFFFFull / per_step;
         int max_k = (int)std::min<unsigned long long>(fit > 1 ? fit - 1 : 1, 0x7FFFFFFFull);
         if (h->tun_max_launch_steps > 0) max_k = std::min(max_k, h->tun_max_launch_steps);   // (tests: force the cut)
+        // L = 6 + 4N is 2 mod 4: one step's observation slab (E x N x L floats) is a multiple of 16 bytes only when E x N is
+        // even; with E x N odd every sub-launch must start on an EVEN step so that its slice of the tensor stays 16-byte
+        // aligned (an odd cut failed on "obs buffer must be 16-byte aligned" after the first sub-launch had
+        // already advanced the state)
+        const bool odd_slab = out.obs && ((((size_t)h->E * h->N * (size_t)(6 + 4 * h->N) * sizeof(float)) & 15u) != 0);
+        if (odd_slab && max_k > 1) max_k &= ~1;
+        if (K > max_k && odd_slab && max_k == 1)
+            return fail(CCX_EINVAL, "a rollout of an odd number of agent slots (E x N = %lld) cannot be cut into launches of "
+                        "one step: its per-step observation slabs are not 16-byte aligned (raise max_launch_steps to >= 2)",
+                        (long long)h->E * h->N);
         if (K > max_k) {
             const size_t EN = (size_t)h->E * h->N, L = (size_t)(6 + 4 * h->N);
             for (int k0 = 0; k0 < K; k0 += max_k) {
@@ -461,6 +495,19 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     if (out.obs_compact && (reinterpret_cast<uintptr_t>(out.obs_compact) & 15u))
         return fail(CCX_EINVAL, "obs_compact buffer must be 16-byte aligned");
     CCX_HIP(hipSetDevice(h->device));
+    if (K <= ccx::kStepMaxK && actions && !order && policy == 0 && !actions_out && h->step_shape.ok && h->tun_step_kernel != 0) {
+        // the short-launch kernel (ccx_step.hip): CollectiveCrossingEnv.step itself, no pacing, no controller state
+        if (h->check_inputs) {
+            hipError_t ce = ccx::launch_check_inputs(h->stream, actions, nullptr, (size_t)K * (size_t)h->E, h->N, h->input_errors);
+            if (ce != hipSuccess) return fail(CCX_EHIP, "input check kernel launch failed: %s", hipGetErrorString(ce));
+        }
+        int rc = begin_timed(h);
+        if (rc) return rc;
+        hipError_t e = ccx::launch_step(h->step_shape, h->stream, h->kp, h->st_slab, h->cell_info, actions, K, auto_reset,
+                                        h->pool, out, h->counters);
+        if (e != hipSuccess) return fail(CCX_EHIP, "step kernel launch failed: %s", hipGetErrorString(e));
+        return end_timed(h);
+    }
     const bool writes_obs = out.obs != nullptr;
     bool capturing = false;
     {
@@ -468,24 +515,32 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
         if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess) (void)hipGetLastError();
         else capturing = cap != hipStreamCaptureStatusNone;
     }
-    if (h->pace_dirty) {   // (re)start the pace controller: new handle, new launch shape or new setting
+    {   // (re)start the pace controller: new handle, new launch shape or new setting
         // Never inside a stream capture: the memsets would become graph nodes and every replay would re-zero the
-        // controller's state, and the calibration must synchronise.  A launch that needs the (re)start is
-        // refused while capturing; run one eager launch of the shape first.
-        if (capturing && ccx::launch_is_paced(h->kp.pace_state != nullptr, writes_obs, K, h->kp.pace_min_k))
-            return fail(CCX_EINVAL, "the pace controller of this handle must be (re)started (new handle, launch shape or "
-                        "setting): run one eager rollout of this shape before capturing it into a graph");
+        // controller's state, and the calibration must synchronise.  Only a launch that would actually run them
+        // is refused while capturing; a controller that has been started (by ANY eager paced launch of the shape) and merely
+        // waits for its calibration captures fine and runs at the pace in effect (K = 16..63 on the C2 shape).
         const bool paced_launch = ccx::launch_is_paced(h->kp.pace_state != nullptr, writes_obs, K, h->kp.pace_min_k);
-        if (!h->kp.pace_state) {
+        const bool adaptive_launch =
+            ccx::launch_is_adaptive(h->kp.pace_state != nullptr, h->kp.pace_adapt != 0u, writes_obs, K, h->kp.pace_min_k, h->kp.adapt_min_k);
+        if (h->pace_dirty && !h->kp.pace_state) {
             h->pace_dirty = false;              // rollouts of this shape are not paced at all
-        } else if (!capturing && paced_launch) {   // (launches that are not paced never look at the controller: nothing to do yet)
-            const bool adaptive_launch =
-                ccx::launch_is_adaptive(h->kp.pace_state != nullptr, h->kp.pace_adapt != 0u, writes_obs, K, h->kp.pace_min_k, h->kp.adapt_min_k);
-            const bool wants_calibration = h->kp.pace_adapt != 0u && h->pace_calibrate && h->pace_start_ns <= 0.0f;
-            if (adaptive_launch && wants_calibration) {
+            h->pace_needs_calibration = false;
+        }
+        if (h->pace_dirty && paced_launch) {    // (launches that are not paced never look at the controller: nothing to do yet)
+            if (capturing)
+                return fail(CCX_EINVAL, "the pace controller of this handle must be (re)started (new handle, launch shape or "
+                            "setting): run one eager rollout of this shape (any paced length: >= %u steps) before capturing it "
+                            "into a graph, or switch pacing off (ccx_set_step_pace(h, -1))", h->kp.pace_min_k);
+            h->pace_needs_calibration = h->kp.pace_adapt != 0u && h->pace_calibrate && h->pace_start_ns <= 0.0f;
+        }
+        const bool calibrate_now = h->pace_needs_calibration && adaptive_launch && !capturing;
+        if ((h->pace_dirty && paced_launch) || calibrate_now) {
+            if (calibrate_now) {
                 const size_t obs_bytes = (size_t)K * (size_t)h->E * h->N * (size_t)(6 + 4 * h->N) * sizeof(float);
                 const int rc = calibrate_pace(h, out.obs, obs_bytes);
                 if (rc) return rc;
+                h->pace_needs_calibration = false;
             }
             CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state), 0, 8, h->stream));   // floor, cliff memory = 0
             CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state + h->pace_slot),
@@ -497,8 +552,9 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
             // so the controller descends from it at its fast rate (1.6 % per launch) until the memory side says stop.
             if (h->step_pace_ns == 0 && h->pace_start_ns > 0.0f)
                 CCX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->pace_state + 2), (int)h->pace_init_fp, 1, h->stream));
-            // (a paced launch too short to calibrate on keeps the assumption; the first long one calibrates and restarts)
-            h->pace_dirty = wants_calibration && !adaptive_launch;
+            // (a paced launch too short to calibrate on runs from the assumption; the first adaptive eager one calibrates
+            // and restarts: pace_needs_calibration)
+            h->pace_dirty = false;
         }
     }
     h->kp.pace_slot = h->pace_slot;
@@ -545,7 +601,7 @@ int ccx_abi_version(void) { return CCX_ABI_VERSION; }
 
 const char* ccx_build_info(void) {
     static char buf[128];
-    snprintf(buf, sizeof(buf), "libccx 0.4.0 abi %d gfx950 hip %d.%d", CCX_ABI_VERSION,
+    snprintf(buf, sizeof(buf), "libccx 0.5.0 abi %d gfx950 hip %d.%d", CCX_ABI_VERSION,
              HIP_VERSION_MAJOR, HIP_VERSION_MINOR);
     return buf;
 }
@@ -593,13 +649,19 @@ int ccx_create(const ccx_params* params, int32_t num_envs, int64_t env_offset, i
     auto alloc = [&](void** p, size_t bytes) {
         if (e == hipSuccess) e = hipMalloc(p, bytes);
     };
-    alloc((void**)&h->st.x, en * 4);
-    alloc((void**)&h->st.y, en * 4);
-    alloc((void**)&h->st.active, en);
-    alloc((void**)&h->st.terminated, en);
-    alloc((void**)&h->st.truncated, en);
-    alloc((void**)&h->st.step_count, (size_t)h->E * 4);
-    alloc((void**)&h->st.episode, (size_t)h->E * 4);
+    {   // the seven state arrays: ONE allocation (ccx_kernels.h: StateSlab), so that the short-launch kernel needs one pointer
+        const ccx::StateSlab sl = ccx::state_slab(h->E, h->N);
+        alloc((void**)&h->st_slab, sl.total);
+        if (e == hipSuccess) {
+            h->st.x = reinterpret_cast<int32_t*>(h->st_slab + sl.x);
+            h->st.y = reinterpret_cast<int32_t*>(h->st_slab + sl.y);
+            h->st.active = h->st_slab + sl.active;
+            h->st.terminated = h->st_slab + sl.terminated;
+            h->st.truncated = h->st_slab + sl.truncated;
+            h->st.step_count = reinterpret_cast<int32_t*>(h->st_slab + sl.step_count);
+            h->st.episode = reinterpret_cast<int32_t*>(h->st_slab + sl.episode);
+        }
+    }
     alloc((void**)&h->counters, ccx::counter_words(h->E) * sizeof(unsigned long long));
     alloc((void**)&h->placement_scratch, en * 2);
     alloc((void**)&h->pace_state, 8 * sizeof(uint32_t));
@@ -645,13 +707,7 @@ void ccx_destroy(ccx_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(h->st.x);
-    (void)hipFree(h->st.y);
-    (void)hipFree(h->st.active);
-    (void)hipFree(h->st.terminated);
-    (void)hipFree(h->st.truncated);
-    (void)hipFree(h->st.step_count);
-    (void)hipFree(h->st.episode);
+    (void)hipFree(h->st_slab);
     (void)hipFree(h->counters);
     (void)hipFree(h->pace_state);
     (void)hipFree(h->input_errors);
@@ -987,8 +1043,13 @@ int ccx_set_policy_stream(ccx_handle* h, int32_t kind, const uint32_t* seeds, ui
         hipError_t e = ccx::launch_policy_stream_seed(h->stream, h->mt_state, seeds_dev, seed, h->E);
         hipError_t se = hipStreamSynchronize(h->stream);      // (the seeds array may be freed by the caller on return)
         if (seeds_dev) (void)hipFree(seeds_dev);
-        if (e != hipSuccess) return fail(CCX_EHIP, "stream seeding kernel launch failed: %s", hipGetErrorString(e));
-        if (se != hipSuccess) return fail(CCX_EHIP, "stream seeding failed: %s", hipGetErrorString(se));
+        if (e != hipSuccess || se != hipSuccess) {
+            // (a half-seeded generator array must not be handed out by ccx_get_policy_stream or walked by a policy kernel)
+            (void)hipFree(h->mt_state);
+            h->mt_state = nullptr;
+            h->eps_stream = CCX_EPS_STREAM_COUNTER;
+            return fail(CCX_EHIP, "stream seeding failed: %s", hipGetErrorString(e != hipSuccess ? e : se));
+        }
     }
     h->eps_stream = kind;
     return CCX_OK;
@@ -1112,6 +1173,9 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
         {"writer_roles", &h->tun_writer_roles, -1, 1},
         {"max_launch_steps", &h->tun_max_launch_steps, 0, 0x7FFFFFFF},
         {"pair_rows", &h->tun_pair_rows, -1, 1},
+        {"step_kernel", &h->tun_step_kernel, -1, 1},
+        {"step_rows", &h->tun_step_rows, 0, 7},
+        {"step_lanes", &h->tun_step_lanes, 0, 64},
     };
     for (auto& t : table)
         if (strcmp(name, t.name) == 0) {
@@ -1120,7 +1184,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
             *t.slot = value;
             return choose_shape(h);
         }
-    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, hand2, writer_roles, max_launch_steps, pair_rows)", name);
+    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, hand2, writer_roles, max_launch_steps, pair_rows, step_kernel, step_rows, step_lanes)", name);
 }
 
 int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {
@@ -1169,6 +1233,18 @@ int ccx_get_launch_shape(ccx_handle* h, int32_t* lanes_per_wave, int32_t* waves_
     if (waves_per_block) *waves_per_block = h->shape.waves_per_block;
     if (group_lanes) *group_lanes = 1 << h->shape.glog;
     if (num_blocks) *num_blocks = h->shape.num_blocks;
+    return CCX_OK;
+}
+
+int ccx_get_step_shape(ccx_handle* h, int32_t* ok, int32_t* lanes_per_wave, int32_t* row_waves,
+                       int32_t* num_blocks, int32_t* lds_bytes) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    const ccx::StepShape& ss = h->step_shape;
+    if (ok) *ok = (ss.ok && h->tun_step_kernel != 0) ? 1 : 0;
+    if (lanes_per_wave) *lanes_per_wave = ss.envs_per_wave << ss.glog;
+    if (row_waves) *row_waves = ss.row_waves;
+    if (num_blocks) *num_blocks = ss.num_blocks;
+    if (lds_bytes) *lds_bytes = (int32_t)ss.lds_bytes;
     return CCX_OK;
 }
 

@@ -31,6 +31,7 @@ struct ccx_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     ccx::KState st{};
+    uint8_t* st_slab = nullptr;              // ONE allocation behind the seven state arrays (ccx_kernels.h: StateSlab)
     unsigned long long* cell_info = nullptr; // per-cell geometry table (see ccx_kernels.hip: CellInfo)
     uint8_t* placement_scratch = nullptr;    // u8 [E][N][2] work area of ccx_reset_seeded
     unsigned long long* counters = nullptr;  // 6 x u64 (+ 10 spare words used by diagnostic builds)
@@ -45,6 +46,7 @@ struct ccx_handle {
     uint32_t* pace_state = nullptr;                            // device: current pace (ticks x 256)
     uint32_t pace_init_fp = 0;                                 // value to (re)start the controller from
     bool pace_dirty = true;                                    // pace_state must be rewritten before a launch
+    bool pace_needs_calibration = false;                       // the controller runs from the assumed start value: the first ADAPTIVE eager launch calibrates and restarts it
     uint16_t* obs_table = nullptr;                             // device: obs address table of the current shape
     std::vector<uint16_t> obs_table_host;
     uint32_t pace_slot = 0;                                    // slot of pace_state the next launch reads
@@ -65,6 +67,9 @@ struct ccx_handle {
     float* stream_obs = nullptr;                               // device f32 [E][N][L]: aligned staging slab of that loop
     bool check_inputs = false;                                 // ccx_set_check_inputs
     unsigned long long* input_errors = nullptr;                // device [2]: bad action bytes, bad order rows
+    int tun_step_kernel = -1;                                   // launches of <= 16 steps: -1 / 1 the short-launch kernel (ccx_step.hip) where it applies, 0 always the rollout kernel
+    int tun_step_rows = 0, tun_step_lanes = 0;                  // short-launch kernel: row waves per tile (0 = default), lanes per wave carrying agents (0 = default)
+    ccx::StepShape step_shape{};
     ccx::LaunchShape shape{};
     ccx::KParams kp{};
 };

@@ -117,7 +117,7 @@ struct KParams {
     // tunables (ccx_set_tunable): how the tiles' step schedules are phased, how workgroups map to tiles
     uint32_t pace_phase, tile_map;
     uint32_t wp_magic;                   // ceil(2^32 / (W + 3)): cell index / row length by one multiply-high (exact below 2^17)
-    uint32_t stage_slots;                // slots of the sim -> writer hand-off ring (a power of two, 2..8)
+    uint32_t stage_slots;                // slots of the sim -> writer hand-off ring (a power of two: 16 or 32, ccx_api.hip: choose_shape)
     uint32_t hand_flags;                 // 1: sequence-word hand-off between sim and writer waves (unpaced launches), 0: one barrier per step
     uint32_t writer0_small;              // 1: writer 0 writes the small outputs only, writers 1.. the observation rows
     uint32_t rng_lo, rng_hi;             // seed of CCX_POLICY_RANDOM and of the epsilon draws (ccx_set_rng_seed)
@@ -139,6 +139,17 @@ struct KState {
     int32_t* step_count;
     int32_t* episode;
 };
+
+// The handle's state arrays live in ONE device allocation (ccx_api.hip: ccx_create): the short-launch kernel gets one base
+// pointer (a preloaded kernel argument) and derives the seven arrays from E and N.
+struct StateSlab { size_t x, y, active, terminated, truncated, step_count, episode, total; };
+__host__ __device__ inline StateSlab state_slab(int E, int N) {
+    const size_t en = ((size_t)E * (size_t)N + 63u) & ~(size_t)63u, e = ((size_t)E + 63u) & ~(size_t)63u;
+    StateSlab s;
+    s.x = 0; s.y = 4u * en; s.active = 8u * en; s.terminated = 9u * en; s.truncated = 10u * en;
+    s.step_count = 11u * en; s.episode = 11u * en + 4u * e; s.total = 11u * en + 8u * e;
+    return s;
+}
 
 struct KOut {
     float* obs;
@@ -185,6 +196,18 @@ struct LaunchShape {
     size_t lds_bytes;        // rollout kernel: cell table + per-wave tiles + obs table
     size_t lds_bytes_observe;  // observe kernel: per-wave tiles + obs table
 };
+
+// launch shape of the short-launch kernel (ccx_step.hip): a workgroup = one tile = a sim wave + row_waves row waves
+struct StepShape {
+    int ok;               // 0: this handle's short launches take the rollout kernel (tables too large for LDS)
+    int glog, envs_per_wave, row_waves, num_blocks;
+    size_t lds_bytes;
+};
+constexpr int kStepMaxK = 16;   // env-steps per launch of the short-launch kernel (one burst of action loads)
+size_t step_lds_bytes(int glog, int ew, int N, int cells);
+hipError_t launch_step(const StepShape& ss, hipStream_t stream, const KParams& p, uint8_t* st_base,
+                       const unsigned long long* cell_info, const uint8_t* actions, int K, int auto_reset,
+                       const uint8_t* pool, const KOut& out, unsigned long long* counters);
 
 hipError_t launch_rollout(const LaunchShape& ls, hipStream_t stream, const KParams& p,
                           const KState& st, const unsigned long long* cell_info,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CCX_ABI_VERSION 4
+#define CCX_ABI_VERSION 5
 
 typedef enum ccx_status {
     CCX_OK = 0,
@@ -440,6 +440,14 @@ int ccx_get_residency(ccx_handle* h, int32_t* resident_workgroups, int32_t* work
 int ccx_get_writer_shape(ccx_handle* h, int32_t* writers_per_tile, int32_t* max_stores_in_flight);
 int ccx_get_launch_shape(ccx_handle* h, int32_t* lanes_per_wave, int32_t* waves_per_block,
                          int32_t* group_lanes, int32_t* num_blocks);
+/* Launch shape of the SHORT-LAUNCH kernel (csrc/ccx_step.hip): ccx_step and ccx_rollout calls of at most 16 steps with an
+ * action tensor and no move order are CollectiveCrossingEnv.step itself (collectivecrossing.py:161-261) with one workgroup
+ * per env tile -- a sim wave plus *row_waves waves that gather the observation rows, one LDS barrier per step, no ring, no
+ * pacing.  *ok = 0: this handle's short launches take the rollout kernel (grid too large for the LDS tables).  Tunables:
+ * "step_kernel" (0 = always the rollout kernel), "step_rows" (row waves per tile), "step_lanes" (lanes per wave carrying
+ * agents). */
+int ccx_get_step_shape(ccx_handle* h, int32_t* ok, int32_t* lanes_per_wave, int32_t* row_waves,
+                       int32_t* num_blocks, int32_t* lds_bytes);
 
 /* Zero-copy I/O for single-env stepping (the dict API of collectivecrossing.py:161-261 needs every
  * output on the host after each step): the device address of page-locked host memory (hipHostMalloc /

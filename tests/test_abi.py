@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     from collectivecrossing_amd import _abi
 
-    assert lib.ccx_abi_version() == _abi.ABI_VERSION == 4
+    assert lib.ccx_abi_version() == _abi.ABI_VERSION == 5
     assert lib.ccx_obs_len(8) == 38 and lib.ccx_obs_len(3) == 18
     assert b"gfx950" in lib.ccx_build_info()
 

@@ -43,9 +43,7 @@ def test_flat_api_replays_the_recorded_reference_episodes(name):
     assert split_id("17/boarding_3") == (17, "boarding_3")
     # start every env from the recorded initial state (the recordings begin after reset(seed))
     env.reset(seed=0)
-    env.vector.batch.set_state(**g.init_state())
-    import torch
-    env.vector._done.copy_(torch.from_numpy((g["init_terminated"] | g["init_truncated"]).astype(bool)))
+    env.set_state(**g.init_state())
     running = list(range(g.E))
     for s in range(g.K):
         if not running:
@@ -105,5 +103,48 @@ def test_factory_reset_and_finished_envs():
     assert all(np.array_equal(obs2[k], obs[k]) for k in obs) and env.agents == env.possible_agents
     with pytest.raises(RuntimeError, match="batch"):
         env.vector.envs[0].step({})
+    probe.close()
+    env.close()
+
+
+def test_auto_reset_restarts_each_env_behind_its_own_all_flag():
+    """RLlib restarts an env when ITS `__all__` rises (examples/training_script.py:26-29, 69-86).  With auto_reset the flat
+    env does that per env on the device: the finishing step returns the finished step's rewards / flags, the NEW episode's
+    first observations (= the reference's reset(seed0 + episode * E + e), checked against the single-env class) and the
+    finished episode's own dicts under infos["<e>/__final__"]; the batch never drains and the flat `__all__` stays False."""
+    from collectivecrossing_amd import CollectiveCrossingEnv
+    from collectivecrossing_amd import configs as C
+    from collectivecrossing_amd.rllib import BatchedMultiAgentEnv
+    env_config = dict(width=12, height=8, division_y=4, tram_door_left=5, tram_door_right=7, tram_length=9,
+                      num_boarding_agents=3, num_exiting_agents=2, exiting_destination_area_y=0,
+                      boarding_destination_area_y=8, truncated_config=C.MaxStepsTruncatedConfig(max_steps=3))
+    E, seed0 = 4, 1000
+    env = BatchedMultiAgentEnv.from_env_config({**env_config, "num_envs": E, "auto_reset": True, "seed0": seed0})
+    probe = CollectiveCrossingEnv(config=C.CollectiveCrossingConfig(**env_config))
+    env.reset(seed=5)
+    # make env 2 finish one step earlier than the others: its step counter starts at 1
+    st = env.vector.batch.get_state()
+    st["step_count"][2] = 1
+    env.set_state(**{k: st[k] for k in ("x", "y", "active", "terminated", "truncated", "step_count")})
+    episodes = np.zeros(E, int)
+    for t in range(7):
+        o, r, te, tr, inf = env.step({a: 4 for a in env.agents})
+        assert not te["__all__"] and not tr["__all__"]
+        finals = sorted(int(k.split("/")[0]) for k in inf if k.endswith("/__final__"))
+        expected = [e for e in range(E) if (t + 1 + (1 if e == 2 else 0)) % 3 == 0]
+        assert finals == expected, (t, finals)
+        for e in finals:
+            episodes[e] += 1
+            fo, fr, fte, ftr, finf = inf[f"{e}/__final__"]
+            assert ftr["__all__"] and not fte["__all__"] and set(fr) == {"boarding_0", "boarding_1", "boarding_2", "exiting_0", "exiting_1"}
+            assert all(tr[f"{e}/{a}"] for a in fr)                      # the finished step's own flags, flat keys
+            want, winfo = probe.reset(seed=seed0 + int(episodes[e]) * E + e)
+            for a in want:
+                assert np.array_equal(o[f"{e}/{a}"], want[a]) and inf[f"{e}/{a}"] == winfo[a]
+        assert len(env.agents) == E * 5                                 # everybody is live again
+    # the device path saw the restarts too: the next step starts from the new placements
+    o, r, te, tr, inf = env.step({a: 4 for a in env.agents})
+    assert len(o) == E * 5
+    assert set(env.last_step_host_us) == {"encode", "launch_and_copy", "dicts", "total"}
     probe.close()
     env.close()

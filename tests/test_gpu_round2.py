@@ -692,3 +692,55 @@ def test_short_rollouts_of_large_tiles_are_adaptive_too(oracle, ccx):
     assert len({round(p, 1) for p in paces}) > 3, (ps, paces)          # the controller moves (down on a healthy box)
     env.close()
     _against_oracle(oracle, ccx, g, E=1500, K=9, seed=77)             # (9 steps: adaptive for this shape) == the oracle
+
+
+# ---- round 4: ADVICE r3 ---------------------------------------------------------------------------------------------
+def test_a_short_paced_rollout_captures_after_one_eager_launch(ccx):
+    """on the C2 shape launches of 16..63 steps are paced but not adaptive; with the calibration pending the
+    handle stayed `dirty` after every such eager launch and refused the capture the caller had prepared for ("run one eager
+    rollout of this shape before capturing").  The pending calibration is tracked apart from the controller's (re)start now:
+    one eager K = 32 launch starts the controller, the same launch captures and replays, and the controller's state is
+    untouched by the replays; a later eager adaptive launch still calibrates."""
+    import torch
+
+    from bench import c2_config
+    E, K = 4096, 32
+    env = ccx(c2_config(), E)
+    env.make_reset_pool(0, 256)
+    env.reset_from_pool()
+    acts = torch.randint(0, 5, (64, E, env.num_agents), dtype=torch.uint8, device=env.device)
+    traj = env.alloc_rollout(K)
+    side = torch.cuda.Stream(device=env.device)
+    env.use_stream(side)
+    with torch.cuda.stream(side):
+        env.rollout(acts[:K], auto_reset=True, out=traj)       # eager, paced, not adaptive: starts the controller
+        side.synchronize()
+        before = env.pace_state()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            env.rollout(acts[:K], auto_reset=True, out=traj)
+        for _ in range(3):
+            graph.replay()
+        side.synchronize()
+        after = env.pace_state()
+        assert after["next_pace_ns"] == before["next_pace_ns"] and after["floor_ns"] == before["floor_ns"]
+        assert env.pace_start()["source"] == "assumed"
+        long_traj = env.alloc_rollout(64)
+        env.rollout(acts, auto_reset=True, out=long_traj)      # the first adaptive eager launch calibrates and restarts
+        side.synchronize()
+        assert env.pace_start()["source"] == "calibration"
+    env.close()
+
+
+def test_cut_rollouts_of_an_odd_number_of_agent_slots_stay_aligned(ccx, oracle):
+    """L = 6 + 4N is 2 mod 4, so a step's observation slab is a multiple of 16 bytes only if E x N is even; with
+    E x N odd a cut after an odd number of steps handed the second sub-launch a misaligned slice ("obs buffer must be
+    16-byte aligned") after the first had advanced the state.  Cuts fall on even steps now."""
+    g = Golden("g7_n5_odd")
+    E, K = 37, 23
+    assert (E * g.N) % 2 == 1
+
+    def setup(env):
+        env.set_tunable("max_launch_steps", 7)
+
+    _against_oracle(oracle, ccx, g, E, K, seed=11, setup=setup)
