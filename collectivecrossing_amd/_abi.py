@@ -135,6 +135,8 @@ PROTOTYPES: dict[str, tuple] = {
     "ccx_get_residency": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccx_get_writer_shape": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccx_get_step_shape": (C.c_int, [_H] + [C.POINTER(C.c_int32)] * 5),
+    "ccx_set_reward_table": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "ccx_set_terminated_table": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "ccx_get_launch_shape": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccx_host_device_pointer": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_void_p)]),

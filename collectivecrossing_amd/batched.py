@@ -24,7 +24,7 @@ import torch
 from . import _abi
 from ._lib import check, load
 from .configs import CollectiveCrossingConfig
-from .params import agent_ids, lower_config
+from .params import agent_ids, lower_config, position_only_tables
 from .reset import build_reset_pool, seeded_positions
 
 
@@ -59,7 +59,9 @@ class BatchedCollectiveCrossing:
                  env_offset: int = 0, total_envs: int | None = None, check_inputs: bool | None = None):
         self._lib = load()
         self.config = config
-        self.params = lower_config(config)
+        # (position-only user strategies -- strategies.RewardFunction.position_only -- run inside the kernels as tables)
+        self.params = lower_config(config, allow_position_only=True)
+        self._user_tables = position_only_tables(config)
         self.num_envs = int(num_envs)
         self.num_agents = self.params.num_agents
         self.obs_len = 6 + 4 * self.num_agents
@@ -88,6 +90,11 @@ class BatchedCollectiveCrossing:
             check_inputs = os.environ.get("CCX_CHECK_INPUTS", "0") not in ("", "0")
         if check_inputs:
             self.set_check_inputs(True)
+        rew, term = self._user_tables
+        if term is not None:
+            self.set_terminated_table(*term)
+        if rew is not None:
+            self.set_reward_table(*rew)
         self._apply_pace_memory()
 
     # ------------------------------------------------------------------ lifetime
@@ -410,7 +417,11 @@ class BatchedCollectiveCrossing:
     @staticmethod
     def _pace_cache_path() -> Path | None:
         p = os.environ.get("CCX_PACE_CACHE")
-        if not p or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        try:
+            world = int(os.environ.get("WORLD_SIZE", "1") or "1")
+        except ValueError:                     # (an empty or non-numeric value must not break handle construction: ADVICE r3)
+            world = 1
+        if not p or world > 1:
             return None
         return Path(p)
 
@@ -521,6 +532,30 @@ class BatchedCollectiveCrossing:
         return dict(zip(("lanes_per_wave", "waves_per_block", "group_lanes", "num_blocks",
                          "writers_per_tile", "store_throttle", "resident_blocks"),
                         (int(x.value) for x in v + w + r[:1])))
+
+    def set_reward_table(self, boarding, exiting) -> None:
+        """Per-(agent type, cell) rewards, f64 ``[height + 1, width + 1]`` each (``ccx_set_reward_table``): what a
+        position-only user ``RewardFunction`` (rewards.py:16-38) is lowered to.  ``None, None`` restores the built-in reward."""
+        if boarding is None and exiting is None:
+            check(self._lib.ccx_set_reward_table(self._h, None, None))
+        else:
+            shape = (self.config.height + 1, self.config.width + 1)
+            b, e = (np.ascontiguousarray(t, np.float64) for t in (boarding, exiting))
+            if b.shape != shape or e.shape != shape:
+                raise ValueError(f"reward tables must be {shape} (rows y, columns x), got {b.shape} / {e.shape}")
+            check(self._lib.ccx_set_reward_table(self._h, b.ctypes.data, e.ctypes.data))
+        self._shape_changed()
+
+    def set_terminated_table(self, boarding, exiting) -> None:
+        """Per-(agent type, cell) ``terminateds[id]`` values, u8 ``[height + 1, width + 1]`` each (``ccx_set_terminated_table``)."""
+        if boarding is None and exiting is None:
+            check(self._lib.ccx_set_terminated_table(self._h, None, None))
+            return
+        shape = (self.config.height + 1, self.config.width + 1)
+        b, e = (np.ascontiguousarray(np.asarray(t) != 0, np.uint8) for t in (boarding, exiting))
+        if b.shape != shape or e.shape != shape:
+            raise ValueError(f"terminated tables must be {shape} (rows y, columns x), got {b.shape} / {e.shape}")
+        check(self._lib.ccx_set_terminated_table(self._h, b.ctypes.data, e.ctypes.data))
 
     def step_shape(self) -> dict[str, int]:
         """Launch shape of the short-launch kernel (``ccx_get_step_shape``): ``ok`` = 1 when ``step`` / rollouts of at most

@@ -46,7 +46,7 @@ namespace {
 // Per-cell geometry table of the padded grid (layout: ccx_kernels.hip, struct CellInfo).  This is
 // config lowering, done once per handle: the reference evaluates the same predicates per agent
 // per step (collectivecrossing.py:509-534, 551-563, 663-683; rewards.py:44-182).
-std::vector<unsigned long long> build_cell_table(const ccx_params& p) {
+std::vector<unsigned long long> build_cell_table(const ccx_params& p, const std::vector<uint8_t>* term_table = nullptr) {
     const int Wp = p.width + 3, Hp = p.height + 3;
     const int dc = (p.door_left + p.door_right) / 2;
     auto cell_ok = [&](int x, int y) {   // collectivecrossing.py:509-534
@@ -77,9 +77,14 @@ std::vector<unsigned long long> build_cell_table(const ccx_params& p) {
                 sd_b = -(y > p.boarding_dest_y ? y - p.boarding_dest_y : p.boarding_dest_y - y);
                 sd_e = -(y > p.exiting_dest_y ? y - p.exiting_dest_y : p.exiting_dest_y - y);
             }
+            // terminateds[id] on this cell (terminateds.py:66-82): the destination row, or the user's table
+            const size_t ci = (size_t)y * (size_t)(p.width + 1) + (size_t)x;
+            const bool term_b = (term_table && !term_table[0].empty()) ? term_table[0][ci] != 0 : dest_b;
+            const bool term_e = (term_table && !term_table[1].empty()) ? term_table[1][ci] != 0 : dest_e;
             unsigned lo = nv | (in_area ? ccx::kCellInTram : 0u) | (at_door ? ccx::kCellAtDoor : 0u) |
-                          ((dest_b ? 1u : 0u) << 8) | (cls_b << 9) | ((dest_e ? 1u : 0u) << 12) |
-                          (cls_e << 13) | ((unsigned)x << 16) | ((unsigned)y << 24);
+                          ((dest_b ? 1u : 0u) << 8) | (cls_b << 9) | ((term_b ? 1u : 0u) << (8 + ccx::kCellTermShift)) |
+                          ((dest_e ? 1u : 0u) << 12) | (cls_e << 13) | ((term_e ? 1u : 0u) << (12 + ccx::kCellTermShift)) |
+                          ((unsigned)x << 16) | ((unsigned)y << 24);
             unsigned hi = ((unsigned)sd_b & 0xFFFFu) | (((unsigned)sd_e & 0xFFFFu) << 16);
             tab[(size_t)(y + 1) * Wp + (x + 1)] = (unsigned long long)lo | ((unsigned long long)hi << 32);
         }
@@ -91,7 +96,10 @@ std::vector<unsigned long long> build_cell_table(const ccx_params& p) {
 // EW is, so the batch should be cut into at least ~512 tiles (1024 waves = one per SIMD of the
 // 256 CUs) before tiles are made fuller.  Measured on 4096 envs x 8 agents: 64 lanes/wave
 // (512 tiles) 0.252 ms per 250 steps, 32 lanes 0.280 ms, 16 lanes 0.344 ms.
-int choose_shape(ccx_handle* h) {
+// rows: the shape of launches that write observation rows (h->shape / h->kp: paced, sized for the row stream);
+// !rows: the shape of launches without them (h->shape_small / h->kp_small: rewards, flag bytes, compact rows -- bound by
+// the sim chain and by how many tiles are resident, profiles/r04_shape_sweep.json).
+int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KParams& k) {
     const int glog = ceil_log2(h->N);
     const int G = 1 << glog;
     const int max_ew = 64 / G;
@@ -114,8 +122,8 @@ int choose_shape(ccx_handle* h) {
         const size_t msz_ = (glog == 6) ? 8u : 4u;
         auto need = [&](int e) {
             const size_t units_ = (size_t)e * h->N * (3 + 2 * h->N);
-            return up(cells_ * 8u) + up(ccx::tile_head_bytes(16) + 7u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) +
-                   up((units_ + 2u) * 2u);
+            return up(cells_ * 8u) + (h->reward_table ? up(cells_ * 16u) : 0u) +
+                   up(ccx::tile_head_bytes(16) + 7u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) + up((units_ + 2u) * 2u);
         };
         if (need(1) <= 96u * 1024u)
             while (ew > 1 && need(ew) > 96u * 1024u) ew >>= 1;
@@ -139,7 +147,8 @@ int choose_shape(ccx_handle* h) {
             // two let a 6 x 16 grid with one agent per env through whose full tile then lost its occupancy tables, and
             // with them the in-kernel policies; found by the round-3 hypothesis soak)
             const size_t wslots_ = (size_t)(h->writers > 0 ? h->writers : 4) * 1056u;
-            if (up(cells_ * 8u) + up(ccx::tile_head_bytes(16) + wslots_ + up((size_t)max_ew * 2u * (cells_ + 1u) * msz_)) +
+            if (up(cells_ * 8u) + (h->reward_table ? up(cells_ * 16u) : 0u) +
+                    up(ccx::tile_head_bytes(16) + wslots_ + up((size_t)max_ew * 2u * (cells_ + 1u) * msz_)) +
                     up((units_ + 2u) * 2u) <= 96u * 1024u) {
                 small_batch = true;
                 ew = max_ew;
@@ -147,7 +156,9 @@ int choose_shape(ccx_handle* h) {
                 // each put a tile on every CU and halve each writer's share (round 3, us per env-step with full outputs:
                 // 1024 envs 0.355 vs 0.398-0.402 with full tiles and 3-4 writers, 512 envs 0.353 vs 0.395).  What remains
                 // is the step's own latency chain sim -> hand-off -> writer (~0.35 us), not bytes.
-                if (full_tiles <= 128 && max_ew >= 2 && h->writers == 0) {
+                // (round 4 sweep: only where a full tile has >= 9 store iterations per step -- with fewer the row work is too
+                // small to be worth two half-width sim waves: 3 agents, 256-2048 envs 0.37-0.39 vs 0.34 us per env-step)
+                if (full_tiles <= 128 && max_ew >= 2 && h->writers == 0 && (!rows || full_n4 >= 64 * 9)) {
                     ew = max_ew / 2;
                     half_tiles = true;
                 }
@@ -173,10 +184,26 @@ int choose_shape(ccx_handle* h) {
     // C2 was bound by its writer wave, not by memory; with two the pace follows the memory side down to
     // ~0.70 us: 0.86 -> 0.92 of the HBM peak in one call (round 2; round 1 measured two writers as no gain,
     // but its sim wave was 20 % slower and hid the difference).
+    // Writer waves per tile (round 4: re-derived from the E x N x output-mode sweep, profiles/r04_shape_sweep.json, which
+    // measures every (lanes, writers) candidate per point; the tables of DESIGN.md 4 are that file):
+    //   launches WITHOUT observation rows (rewards / flag bytes / compact rows: bound by the sim chain and by how many tiles
+    //     are resident): two writers split by role, ONE from 1024 tiles on (8 agents, 16 384 envs: 0.55 vs 0.91 us per
+    //     env-step with two; 32 agents, 32 768 envs: 4.1 vs 6.3) -- lane groups of 32 / 64 only from 16 384 tiles on (their
+    //     compact rows keep a second writer busy), single-agent envs never (one writer: +30-40 %);
+    //   small batches (unpaced, full or half tiles): 3-4 writers split by role, as measured in round 3;
+    //   large tiles (> 24 store iterations per step): 3;
+    //   small tiles (<= 12 iterations, C2): two writers split by role while 3 waves per tile fit one round (three when a
+    //     tile has <= 8 iterations: 3 agents, 8192 envs 0.38 vs 0.47 us); beyond one round THREE (two tiles per workgroup =
+    //     8 waves, two workgroups per CU) -- the single throttled writer of rounds 1-3 was within 2 % of it for 8 agents but
+    //     lost 20-100 % for 1-3 agents (N = 1, 65 536 envs: 2.40 vs 1.17 us) and 17 % for 12 agents at 32 768 envs, and TWO
+    //     writers are a cliff there (6-wave workgroups: +35-80 %);
+    //   tiles in between: 2, or 1 + four tiles per workgroup when that makes the batch fit one round (C3, below).
+    const long long cap_waves = 16ll * h->num_cus;
     int writers = h->writers > 0 ? h->writers
-                  : small_batch ? (half_tiles || tiles <= 160 ? 4 : (long long)tiles * 4 <= 1100 ? 3 : 2)
+                  : !rows ? (glog <= 1 ? 2 : glog <= 4 ? (tiles >= 1024 ? 1 : 2) : (tiles >= 16384 ? 1 : 2))
+                  : small_batch ? (half_tiles || tiles <= 160 ? 4 : 3)
                   : n4 > 64 * 24 ? 3
-                  : small_tiles ? ((long long)tiles * 3 <= 16ll * h->num_cus ? 2 : 1) : 2;
+                  : small_tiles ? ((long long)tiles * 3 <= cap_waves ? (n4 <= 64 * 8 ? 3 : 2) : 3) : 2;
     if (writers > 7) writers = 7;
     // tiles per workgroup: two small tiles share one cell table / one CU slot (with the throttle:
     // 4.43e9 vs 4.23e9 env-steps/s on C2; 3 or 4 per workgroup leave CUs idle and lose 5-10 %)
@@ -188,15 +215,25 @@ int choose_shape(ccx_handle* h) {
     // resident for the whole launch and the tiles of a step sweep the slab exactly once -- C3 (4096 x 32:
     // 2048 tiles x 4 waves = two rounds) 0.84 -> 0.87 of the HBM peak with 1 writer and 4 tiles per
     // workgroup.  (C5, 67 KB per tile, already fits one round with 3 writers; one writer is too slow there.)
-    if (h->writers == 0 && h->waves_per_block == 0 && !small_tiles) {
-        const long long cap = 16ll * h->num_cus;
+    if (rows && h->writers == 0 && h->waves_per_block == 0 && !small_tiles) {
+        const long long cap = cap_waves;
         if ((long long)tiles * (1 + writers) > cap && (long long)tiles * 2 <= cap && n4 <= 64 * 36) {
             writers = 1;
             tpb = 4;
+        } else if ((long long)tiles * (1 + writers) > cap && writers == 3 && n4 <= 64 * 36) {
+            // several rounds anyway: two writers in one-tile workgroups keep five tiles per CU resident instead of four (C3
+            // geometry, 8192 envs: 21.7 vs 25.2 us per env-step; 32 768 envs 1.01).  NOT with two tiles per workgroup:
+            // six-wave workgroups leave a quarter of a CU's 16 wave slots empty (+40 % at 32 768 envs)
+            // From 8192 tiles on ONE writer (eight tiles per CU resident): 16 384 envs 44.2 vs 49.3 us, 32 768 envs 90 vs 100.
+            if (tiles < 8192) {
+                writers = 2;
+                tpb = 1;
+            } else {
+                writers = 1;
+            }
         }
     }
     while (tpb > 1 && tpb * (1 + writers) > 8) --tpb;   // <= 512 threads per workgroup
-    ccx::LaunchShape& s = h->shape;
     s.glog = glog;
     s.envs_per_wave = ew;
     s.waves_per_block = tpb;
@@ -214,7 +251,8 @@ int choose_shape(ccx_handle* h) {
     const size_t msz = (glog == 6) ? 8u : 4u;
     const size_t occ_bytes = up16((size_t)ew * 2u * (cells + 1u) * msz);
     const size_t table = up16((size_t)(units + 2) * 2u);
-    const size_t off_tiles = up16(cells * 8u);
+    const size_t rtab_bytes = h->reward_table ? up16(cells * 16u) : 0u;        // user reward table behind the cell table
+    const size_t off_tiles = up16(cells * 8u) + rtab_bytes;
     // The hand-off ring takes 32 slots (8 KB) -- or 16 where that costs a CU a resident workgroup: LDS is what bounds the
     // residency of the big-tile shapes (C5-64: 40 KB per workgroup with 4 KB of ring, four per CU; with 8 KB only three).
     // (The sim wave proves "slot free" from a progress value it reads once per 16-step burst: 16 slots are the minimum
@@ -258,7 +296,6 @@ int choose_shape(ccx_handle* h) {
     s.lds_bytes = total;
     s.lds_bytes_observe = up16((size_t)tpb * 1056u + table);
 
-    ccx::KParams& k = h->kp;
     const ccx_params& p = h->params;
     k.W = p.width; k.H = p.height; k.div = p.division_y;
     k.tl = p.tram_left; k.tr = p.tram_right; k.dl = p.door_left; k.dr = p.door_right;
@@ -267,6 +304,9 @@ int choose_shape(ccx_handle* h) {
     k.reward_mode = p.reward_mode; k.term_mode = p.terminated_mode; k.max_steps = p.max_steps;
     k.E = h->E; k.EW = ew; k.waves_per_block = tpb; k.units_per_wave = units; k.writers = writers;
     k.off_tiles = (uint32_t)off_tiles; k.tile_stride = (uint32_t)tile_stride;
+    k.reward_table = h->reward_table;
+    k.off_rtab = h->reward_table ? (uint32_t)up16(cells * 8u) : 0u;
+    k.user_tables = (h->reward_table || !h->term_table[0].empty() || !h->term_table[1].empty()) ? 1u : 0u;
     k.off_ws = (uint32_t)off_ws; k.off_occ = (uint32_t)off_occ;
     k.occ_words = s.occ ? (uint32_t)(occ_bytes / 4u) : 0u;
     k.off_table = (uint32_t)(off_tiles + (size_t)tpb * tile_stride);
@@ -289,7 +329,7 @@ int choose_shape(ccx_handle* h) {
     // A batch whose resident tiles cannot even fill the drain rate at a fast 0.45 us per env-step is
     // bound by the step chain, not by memory: pacing could only cost it (a clock read per step).
     const bool can_saturate = s.step_bytes / 7000.0 >= 450.0;
-    k.pace_state = (h->step_pace_ns == -1 || (h->step_pace_ns == 0 && !can_saturate)) ? nullptr : h->pace_state;
+    k.pace_state = (!rows || h->step_pace_ns == -1 || (h->step_pace_ns == 0 && !can_saturate)) ? nullptr : h->pace_state;
     k.pace_adapt = (h->step_pace_ns == 0) ? 1u : 0u;
     {   // how many steps make a launch worth pacing (~12 us) / long enough to judge its lateness (~50 us), at the assumed rate
         const double step_ns = s.step_bytes / 6800.0;
@@ -301,20 +341,24 @@ int choose_shape(ccx_handle* h) {
 
     // observation address table of this shape (ccx_kernels.h: obs_unit_addr).  Shape changes are rare and
     // never happen inside a graph capture: wait for launches that still read the old table, then copy.
-    h->obs_table_host.assign((size_t)units + 2u, 0);
-    for (int w = 0; w < units; ++w) h->obs_table_host[(size_t)w] = ccx::obs_unit_addr((uint32_t)w, h->N, glog);
-    CCX_HIP(hipStreamSynchronize(h->stream));
-    CCX_HIP(hipMemcpy(h->obs_table, h->obs_table_host.data(), h->obs_table_host.size() * sizeof(uint16_t),
-                      hipMemcpyHostToDevice));
+    if (rows) {
+        h->obs_table_host.assign((size_t)units + 2u, 0);
+        for (int w = 0; w < units; ++w) h->obs_table_host[(size_t)w] = ccx::obs_unit_addr((uint32_t)w, h->N, glog);
+        CCX_HIP(hipStreamSynchronize(h->stream));
+        CCX_HIP(hipMemcpy(h->obs_table, h->obs_table_host.data(), h->obs_table_host.size() * sizeof(uint16_t),
+                          hipMemcpyHostToDevice));
+    }
     k.obs_table = h->obs_table;
     k.pace_min_fp = to_fp(s.step_bytes / 8000.0);    // (the spec peak; round 2 stopped at 7.8 TB/s, which multi-tile-per-CU shapes now reach)
     k.pace_max_fp = to_fp(s.step_bytes / 1100.0);
-    h->pace_init_fp = h->step_pace_ns > 0 ? to_fp((double)h->step_pace_ns)
-                      : h->pace_start_ns > 0.0f ? to_fp((double)h->pace_start_ns) : to_fp(s.step_bytes / 6800.0);
-    h->pace_start_source = h->step_pace_ns > 0 ? CCX_PACE_START_FIXED
-                           : h->pace_start_ns > 0.0f ? CCX_PACE_START_CALLER : CCX_PACE_START_ASSUMED;
-    h->pace_dirty = true;
-    h->pace_needs_calibration = false;
+    if (rows) {
+        h->pace_init_fp = h->step_pace_ns > 0 ? to_fp((double)h->step_pace_ns)
+                          : h->pace_start_ns > 0.0f ? to_fp((double)h->pace_start_ns) : to_fp(s.step_bytes / 6800.0);
+        h->pace_start_source = h->step_pace_ns > 0 ? CCX_PACE_START_FIXED
+                               : h->pace_start_ns > 0.0f ? CCX_PACE_START_CALLER : CCX_PACE_START_ASSUMED;
+        h->pace_dirty = true;
+        h->pace_needs_calibration = false;
+    }
     k.r_dest = p.boarding_destination_reward; k.r_door = p.tram_door_reward;
     k.r_area = p.tram_area_reward; k.r_f = p.distance_penalty_factor;
     k.r_nogoal = p.no_goal_reward; k.r_pen = p.step_penalty;
@@ -347,6 +391,7 @@ int choose_shape(ccx_handle* h) {
     }
     k.tile_map = (uint32_t)(h->tun_tile_map >= 0 ? h->tun_tile_map : auto_map);
 
+    if (!rows) return CCX_OK;
     // Short launches (<= 16 steps, ccx_step.hip): a workgroup = one tile = a sim wave + row waves, as many tiles as the
     // batch allows up to ~4 per CU (a short launch is bound by latency, not by issue), never more envs per wave than the
     // rollout shape (the observation address table of a smaller tile is a prefix of the rollout's).  Row waves: enough that
@@ -358,7 +403,7 @@ int choose_shape(ccx_handle* h) {
         else while (sew > 1 && (h->E + sew - 1) / sew < 4 * h->num_cus) sew >>= 1;
         ss.glog = glog;
         ss.envs_per_wave = sew;
-        ss.lds_bytes = ccx::step_lds_bytes(glog, sew, h->N, (int)cells);
+        ss.lds_bytes = ccx::step_lds_bytes(glog, sew, h->N, (int)cells, h->reward_table != nullptr);
         const int sunits = sew * h->N * (3 + 2 * h->N);
         const int sits = ((h->N % 2 == 0 ? sunits / 2 : sunits) + 63) / 64;
         ss.row_waves = h->tun_step_rows > 0 ? h->tun_step_rows
@@ -367,6 +412,16 @@ int choose_shape(ccx_handle* h) {
         ss.ok = (s.occ && ss.lds_bytes <= 96u * 1024u) ? 1 : 0;
     }
     return CCX_OK;
+}
+
+int choose_shape(ccx_handle* h) {
+    // (seeds / epsilon live in h->kp and survive a re-derivation)
+    const uint32_t rng_lo = h->kp.rng_lo, rng_hi = h->kp.rng_hi, eps_thr = h->kp.eps_thr;
+    int rc = derive_shape(h, true, h->shape, h->kp);
+    if (rc) return rc;
+    rc = derive_shape(h, false, h->shape_small, h->kp_small);
+    h->kp.rng_lo = rng_lo; h->kp.rng_hi = rng_hi; h->kp.eps_thr = eps_thr;
+    return rc;
 }
 
 int validate_params(const ccx_params* p) {
@@ -566,7 +621,11 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     // A launch that is being captured into a HIP graph is replayed with these very arguments: the controller
     // cannot adapt across replays (the slot flip below happens once, at capture time), so such a launch runs
     // at the pace in effect and neither votes nor touches the controller's state.
-    ccx::KParams kp = h->kp;
+    const bool small_launch = !writes_obs && h->tun_small_shape != 0;      // rewards / flag bytes / compact rows only
+    const ccx::LaunchShape& shape = small_launch ? h->shape_small : h->shape;
+    ccx::KParams kp = small_launch ? h->kp_small : h->kp;
+    kp.rng_lo = h->kp.rng_lo; kp.rng_hi = h->kp.rng_hi; kp.eps_thr = h->kp.eps_thr;
+    kp.pace_slot = h->pace_slot;
     // launches the kernel will not pace hand steps to the writer waves through sequence words (ccx_kernels.h: one
     // definition of the launch modes for the host and the kernel)
     kp.hand_flags = ccx::launch_uses_flags(kp.pace_state != nullptr, writes_obs, K, kp.pace_min_k, h->tun_hand2) ? 1u : 0u;
@@ -576,7 +635,7 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
         if (!lag_buf) CCX_HIP(hipMalloc(&lag_buf, 16 * 4096 * sizeof(int)));
         CCX_HIP(hipMemsetAsync(lag_buf, 0x80, 16 * 4096 * sizeof(int), h->stream));
         kp.lag_trace = lag_buf;
-        const int tiles_ = h->shape.num_blocks * h->shape.waves_per_block;
+        const int tiles_ = shape.num_blocks * shape.waves_per_block;
         kp.lag_every = tiles_ >= 16 ? tiles_ / 16 : 1;
         g_lag_buf = lag_buf;
     }
@@ -585,7 +644,7 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     if (adaptive && capturing) kp.pace_adapt = 0u;
     int rc = begin_timed(h);
     if (rc) return rc;
-    hipError_t e = ccx::launch_rollout(h->shape, h->stream, kp, h->st, h->cell_info, actions,
+    hipError_t e = ccx::launch_rollout(shape, h->stream, kp, h->st, h->cell_info, actions,
                                        order, K, auto_reset, h->pool, out, h->counters, policy, actions_out);
     if (e != hipSuccess) return fail(CCX_EHIP, "rollout kernel launch failed: %s", hipGetErrorString(e));
     // the kernel collected the votes for the next pace in the other slot (same condition as in the kernel)
@@ -713,6 +772,7 @@ void ccx_destroy(ccx_handle* h) {
     (void)hipFree(h->input_errors);
     (void)hipFree(h->obs_table);
     (void)hipFree(h->cell_info);
+    (void)hipFree(h->reward_table);
     (void)hipFree(h->placement_scratch);
     (void)hipFree(h->mt_state);
     (void)hipFree(h->stream_actions);
@@ -973,9 +1033,7 @@ int ccx_rollout_policy(ccx_handle* h, int32_t num_steps, int32_t policy, int32_t
         }
         return CCX_OK;
     }
-    if (!h->shape.occ && policy != CCX_POLICY_RANDOM)   // (the stepwise loop above uses the stand-alone policy kernel: any shape)
-        return fail(CCX_EINVAL, "policy rollouts need the LDS occupancy tables, which do not fit for this "
-                    "grid / envs-per-wave; drive ccx_step with ccx_greedy_actions instead");
+    // (grids whose occupancy tables exceed the LDS run the in-kernel policies through the all-pairs exchange: round 4)
     return run_rollout(h, num_steps, nullptr, nullptr, auto_reset ? 1 : 0, ko, policy, actions_out);
 }
 
@@ -993,6 +1051,58 @@ int report_input_errors(ccx_handle* h) {
                 "'no move' / an undefined order", bad[0], bad[1]);
 }
 }  // namespace
+
+int ccx_set_reward_table(ccx_handle* h, const double* boarding_per_cell, const double* exiting_per_cell) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if ((boarding_per_cell == nullptr) != (exiting_per_cell == nullptr))
+        return fail(CCX_EINVAL, "give a table for both agent types, or NULL for both (back to the built-in reward)");
+    CCX_HIP(hipSetDevice(h->device));
+    CCX_HIP(hipStreamSynchronize(h->stream));               // (launches in flight still read the old table)
+    if (!boarding_per_cell) {
+        (void)hipFree(h->reward_table);
+        h->reward_table = nullptr;
+        return choose_shape(h);
+    }
+    const int W1 = h->params.width + 1, H1 = h->params.height + 1, Wp = h->params.width + 3, Hp = h->params.height + 3;
+    const size_t cells = (size_t)Wp * (size_t)Hp;
+    std::vector<double> tab(2u * cells, 0.0);                // padded grid, border cells 0 (never occupied)
+    const double* src[2] = {boarding_per_cell, exiting_per_cell};
+    for (int t = 0; t < 2; ++t)
+        for (int y = 0; y < H1; ++y)
+            for (int x = 0; x < W1; ++x)
+                tab[(size_t)t * cells + (size_t)(y + 1) * Wp + (size_t)(x + 1)] = src[t][(size_t)y * W1 + x];
+    if (!h->reward_table) CCX_HIP(hipMalloc(&h->reward_table, tab.size() * sizeof(double)));
+    CCX_HIP(hipMemcpy(h->reward_table, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    const int rc = choose_shape(h);
+    if (rc) return rc;
+    if (h->shape.lds_bytes > 150u * 1024u || h->shape_small.lds_bytes > 150u * 1024u) {
+        (void)hipFree(h->reward_table);
+        h->reward_table = nullptr;
+        (void)choose_shape(h);
+        return fail(CCX_EINVAL, "the reward table of a %d x %d grid (%zu bytes of LDS) does not fit next to the kernel's tables",
+                    h->params.width, h->params.height, cells * 16u);
+    }
+    return CCX_OK;
+}
+
+int ccx_set_terminated_table(ccx_handle* h, const uint8_t* boarding_per_cell, const uint8_t* exiting_per_cell) {
+    if (!h) return fail(CCX_EINVAL, "NULL handle");
+    if ((boarding_per_cell == nullptr) != (exiting_per_cell == nullptr))
+        return fail(CCX_EINVAL, "give a table for both agent types, or NULL for both (back to the built-in strategy)");
+    if (boarding_per_cell && h->params.terminated_mode != CCX_TERM_INDIVIDUAL_AT_DESTINATION)
+        return fail(CCX_EINVAL, "a terminated table replaces individual_at_destination (terminated_mode 0): per agent, from its own cell");
+    const size_t n = (size_t)(h->params.width + 1) * (size_t)(h->params.height + 1);
+    const uint8_t* src[2] = {boarding_per_cell, exiting_per_cell};
+    for (int t = 0; t < 2; ++t) {
+        h->term_table[t].clear();
+        if (src[t]) h->term_table[t].assign(src[t], src[t] + n);
+    }
+    CCX_HIP(hipSetDevice(h->device));
+    CCX_HIP(hipStreamSynchronize(h->stream));
+    const std::vector<unsigned long long> cell_tab = build_cell_table(h->params, h->term_table);
+    CCX_HIP(hipMemcpy(h->cell_info, cell_tab.data(), cell_tab.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    return choose_shape(h);        // (KParams::user_tables)
+}
 
 int ccx_set_check_inputs(ccx_handle* h, int32_t enabled) {
     if (!h) return fail(CCX_EINVAL, "NULL handle");
@@ -1173,6 +1283,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
         {"writer_roles", &h->tun_writer_roles, -1, 1},
         {"max_launch_steps", &h->tun_max_launch_steps, 0, 0x7FFFFFFF},
         {"pair_rows", &h->tun_pair_rows, -1, 1},
+        {"small_shape", &h->tun_small_shape, 0, 1},
         {"step_kernel", &h->tun_step_kernel, -1, 1},
         {"step_rows", &h->tun_step_rows, 0, 7},
         {"step_lanes", &h->tun_step_lanes, 0, 64},
@@ -1184,7 +1295,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
             *t.slot = value;
             return choose_shape(h);
         }
-    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, hand2, writer_roles, max_launch_steps, pair_rows, step_kernel, step_rows, step_lanes)", name);
+    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, hand2, writer_roles, max_launch_steps, pair_rows, small_shape, step_kernel, step_rows, step_lanes)", name);
 }
 
 int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {

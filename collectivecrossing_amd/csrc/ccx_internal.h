@@ -33,6 +33,8 @@ struct ccx_handle {
     ccx::KState st{};
     uint8_t* st_slab = nullptr;              // ONE allocation behind the seven state arrays (ccx_kernels.h: StateSlab)
     unsigned long long* cell_info = nullptr; // per-cell geometry table (see ccx_kernels.hip: CellInfo)
+    double* reward_table = nullptr;          // device f64 [2][cells of the padded grid]: user reward table (ccx_set_reward_table), null = built-in
+    std::vector<uint8_t> term_table[2];      // host u8 [(H+1)(W+1)] per agent type: user terminated table (ccx_set_terminated_table), empty = built-in
     uint8_t* placement_scratch = nullptr;    // u8 [E][N][2] work area of ccx_reset_seeded
     unsigned long long* counters = nullptr;  // 6 x u64 (+ 10 spare words used by diagnostic builds)
     const uint8_t* pool = nullptr;
@@ -70,6 +72,9 @@ struct ccx_handle {
     int tun_step_kernel = -1;                                   // launches of <= 16 steps: -1 / 1 the short-launch kernel (ccx_step.hip) where it applies, 0 always the rollout kernel
     int tun_step_rows = 0, tun_step_lanes = 0;                  // short-launch kernel: row waves per tile (0 = default), lanes per wave carrying agents (0 = default)
     ccx::StepShape step_shape{};
-    ccx::LaunchShape shape{};
+    int tun_small_shape = 1;                                    // 1: launches without observation rows take their own launch shape (shape_small), 0: the rows shape
+    ccx::LaunchShape shape{};                                   // launches that write observation rows
     ccx::KParams kp{};
+    ccx::LaunchShape shape_small{};                             // launches without them (rewards / flag bytes / compact rows)
+    ccx::KParams kp_small{};
 };

@@ -64,6 +64,9 @@ constexpr uint32_t tile_head_bytes(uint32_t stage_slots) { return kStageOff + st
 constexpr uint32_t kSyncSeq = 0u, kSyncProg = 4u;          // (kSyncProg + writer index, at most 7 writers)
 // bits of the low word of a cell's geometry entry (ccx_kernels.hip: per-cell geometry table); bit 4 is always 0
 constexpr uint32_t kCellInTram = 0x20u, kCellAtDoor = 0x40u;
+// bits 11 / 15: terminateds[id] of a boarding / exiting agent on this cell (terminateds.py:66-82: = the destination-row
+// bits 8 / 12 for the built-in strategies; ccx_set_terminated_table overrides them)
+constexpr uint32_t kCellTermShift = 3u;    // (relative to the type's destination bit)
 
 // ONE definition of how a launch is driven, shared by the host (run_rollout) and the kernel: a launch is PACED when the
 // handle paces its shape, it writes observation rows and is long enough to be worth the clock reads; the pace controller
@@ -124,6 +127,11 @@ struct KParams {
     uint32_t eps_thr;                    // epsilon * 2^32 of the scripted policies (ccx_set_policy_epsilon), 0 = greedy
     uint32_t ws_per_writer;              // staging slots (WSlot) per writer wave: 2 where row writers may take two steps per iteration
     uint32_t pace_min_k, adapt_min_k;    // a launch is paced from pace_min_k steps on, the controller adapts from adapt_min_k on
+    // user reward table (ccx_set_reward_table: position-only RewardFunction plugins, rewards.py:16-38): f64 [2][cells of the
+    // padded grid] (boarding, exiting), staged in LDS at off_rtab behind the cell table; off_rtab = 0: the built-in classes
+    const double* reward_table;
+    uint32_t off_rtab;
+    uint32_t user_tables;                // 1: a user reward / terminated table is set: launch the instantiations that are not PLAIN
 #ifdef CCX_LAG_TRACE
     int* lag_trace;                      // diagnostic build: [16 traced tiles][4096 steps] lag behind the schedule, 10-ns ticks
     int lag_every;                       // every lag_every-th tile is traced
@@ -204,7 +212,7 @@ struct StepShape {
     size_t lds_bytes;
 };
 constexpr int kStepMaxK = 16;   // env-steps per launch of the short-launch kernel (one burst of action loads)
-size_t step_lds_bytes(int glog, int ew, int N, int cells);
+size_t step_lds_bytes(int glog, int ew, int N, int cells, bool reward_table);
 hipError_t launch_step(const StepShape& ss, hipStream_t stream, const KParams& p, uint8_t* st_base,
                        const unsigned long long* cell_info, const uint8_t* actions, int K, int auto_reset,
                        const uint8_t* pool, const KOut& out, unsigned long long* counters);

@@ -38,7 +38,7 @@ static hipError_t launch_rollout_g(const LaunchShape& ls, hipStream_t stream, co
     const size_t tile_region = (size_t)p.EW * p.N * (6 + 4 * p.N) * 4u, slab = (size_t)p.E * p.N * (6 + 4 * p.N) * 4u;
     const bool edges = out.obs && (((tile_region | slab) & 127u) != 0 || (reinterpret_cast<uintptr_t>(out.obs) & 127u) != 0);
     const int outm = want_out ? (edges ? 2 : 1) : 0;
-    const bool plain = order == nullptr && policy == 0;
+    const bool plain = order == nullptr && policy == 0 && p.user_tables == 0u;   // (user reward / terminated tables: the general instantiations)
 #define CCX_GO2(P_, O_, C_)                                                                                  \
     return plain ? launch_rollout_v<GLOG, P_, O_, C_, true>(ls, stream, p, st, cell_info, actions, order, K, \
                                                             auto_reset, pool, out, counters, policy, actions_out) \

@@ -22,7 +22,8 @@
 // Scope: actions from a tensor (no move order, no in-kernel policy), K <= 16 (one burst of action loads), LDS
 // occupancy tables (grids whose tables do not fit take the rollout kernel: ccx_api.hip decides).  Auto-reset from the
 // pool is supported (ccx_rollout with few steps).
-// (Kernel-argument preloading into SGPRs was measured and not kept: csrc/Makefile.)
+// The first 14 argument dwords (state slab, actions, both tables, obs, E, shape words, max_steps) are preloaded into SGPRs
+// (csrc/Makefile: -amdgpu-kernarg-preload-count=14): -0.05 us per step, measured on this kernel.
 #include "ccx_rollout_dev.h"
 
 namespace ccx {
@@ -78,7 +79,8 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
             const uint8_t* __restrict__ pool, const uint32_t pool_size, const uint32_t pool_stride,
             const uint32_t env_offset_mod_pool, const int dc, const int div, const int dl, const int dr,
             const int term_all, const int auto_reset,
-            const double rA, const double rB, const double rC, const double rF) {
+            const double rA, const double rB, const double rC, const double rF,
+            const double* __restrict__ reward_table) {                 // user reward table f64 [2][cells] or null
     using mask_t = typename GroupMask<GLOG>::type;
     constexpr int G = 1 << GLOG;
     constexpr uint32_t msz = sizeof(mask_t);
@@ -99,7 +101,8 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
     const uint32_t EN = (uint32_t)E * (uint32_t)N;
     // LDS of the workgroup: [cell table][occupancy / proposal tables][two staging slots (float4 per lane + row constants)]
     auto up16 = [](uint32_t v) { return (v + 15u) & ~15u; };
-    const uint32_t off_occ = up16(cells * 8u);
+    const uint32_t off_rtab = up16(cells * 8u);                               // (the region exists only with a user reward table)
+    const uint32_t off_occ = off_rtab + (reward_table ? cells * 16u : 0u);
     const uint32_t occ_bytes = up16((uint32_t)EW * 2u * (cells + 1u) * msz);
     const uint32_t off_ws = off_occ + occ_bytes;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -236,6 +239,24 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
         if (c == 3) v = (float)dr;
         wl[lane >> 3].cst[c] = v;
     }
+    // lane constants of the step: computed HERE, while the loads are in flight (pinned with empty asm: the compiler would
+    // otherwise sink them behind the wait, next to their first use -- 280 ns between "tables in LDS" and "state in
+    // registers" in the first stamps of this kernel, profiles/r04_step_k1_tstamps.txt)
+    const mask_t full = full_mask<GLOG>();
+    const mask_t lo_m = in_vgpr(low_mask<mask_t>(i));
+    const mask_t later_m = in_vgpr((mask_t)(~lo_m & ~(mask_t(1) << i)));
+    const mask_t mybit = in_vgpr((mask_t)(mask_t(1) << i));
+    const uint32_t gsh = (uint32_t)lane & ~(uint32_t)(G - 1);
+    const uint32_t cells1 = cells + 1u;
+    const uint32_t g_tab = (g < EW) ? (uint32_t)g : 0u;
+    const uint32_t tab_abs = lds0 + off_occ + g_tab * cells1 * 2u * msz;
+    const uint32_t tab_rel = in_vgpr(tab_abs - (lds0 << TS));
+    const uint32_t dump_addr = in_vgpr(tab_abs + ((valid ? cells : (uint32_t)(lane % Wp)) << (3u + TS)));
+    const unsigned long long lut64 = (unsigned long long)(uint16_t)8 | ((unsigned long long)(uint16_t)(Wp * 8) << 16) |
+                                     ((unsigned long long)(uint16_t)(-8) << 32) |
+                                     ((unsigned long long)(uint16_t)(-Wp * 8) << 48);
+    const uint32_t o_rew = in_vgpr(idx * 8u), o_af = idx, o_ef = (uint32_t)env & 0x0FFFFFFFu, o_cmp = in_vgpr(idx * 16u);
+    const float type_f = boarding ? 0.0f : 1.0f;
     unsigned long long* const cinfo = reinterpret_cast<unsigned long long*>(smem);
 #pragma unroll
     for (int r = 0; r < kCellFirst; ++r) {
@@ -243,20 +264,15 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
         if (cw < cells) cinfo[cw] = c_first[r];
     }
     for (uint32_t cw = (uint32_t)lane + 64u * kCellFirst; cw < cells; cw += 64u) cinfo[cw] = cell_info[cw];
+    if (reward_table) {
+        double* rt = reinterpret_cast<double*>(smem + off_rtab);
+        for (uint32_t t = (uint32_t)lane; t < 2u * cells; t += 64u) rt[t] = reward_table[t];
+    }
+    const uint32_t rt_add = off_rtab + (boarding ? 0u : cells * 8u);
     wave_lds_sync();
     CCX_ST(2);
 
     // ---- state -> registers (as in ccx_rollout_body.inc: position = LDS address of the agent's cell word) -------
-    const mask_t full = full_mask<GLOG>();
-    const mask_t lo_m = low_mask<mask_t>(i);
-    const mask_t later_m = ~lo_m & ~(mask_t(1) << i);
-    const mask_t mybit = mask_t(1) << i;
-    const uint32_t gsh = (uint32_t)lane & ~(uint32_t)(G - 1);
-    const uint32_t cells1 = cells + 1u;
-    const uint32_t g_tab = (g < EW) ? (uint32_t)g : 0u;
-    const uint32_t tab_abs = lds0 + off_occ + g_tab * cells1 * 2u * msz;
-    const uint32_t tab_rel = tab_abs - (lds0 << TS);
-    const uint32_t dump_addr = tab_abs + ((valid ? cells : (uint32_t)(lane % Wp)) << (3u + TS));
     auto lds_or = [](uint32_t addr, mask_t bits) {
         __hip_atomic_fetch_or((__attribute__((address_space(3))) mask_t*)(uintptr_t)addr, bits, __ATOMIC_RELAXED,
                               __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -281,9 +297,6 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
     int left1 = max_steps_m1 - stepc;                // negative from the step on which step_count reaches max_steps
     unsigned long long ci = lds_cell(c8);
     uint32_t ilo = (uint32_t)ci, ihi = (uint32_t)(ci >> 32);
-    const unsigned long long lut64 = (unsigned long long)(uint16_t)8 | ((unsigned long long)(uint16_t)(Wp * 8) << 16) |
-                                     ((unsigned long long)(uint16_t)(-8) << 32) |
-                                     ((unsigned long long)(uint16_t)(-Wp * 8) << 48);
     const uint64_t may_reset_b = __builtin_amdgcn_ballot_w64(use_pool && valid_env);
     const uint64_t slot0_b = __builtin_amdgcn_ballot_w64(valid_env && i == 0);
     const uint32_t reset_bit = use_pool ? (uint32_t)CCX_K_EF_RESET : 0u;
@@ -294,7 +307,6 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
 
     // small outputs: scalar bases + 32-bit lane offsets of step 0, advanced by the streams' strides (a launch of <= 16
     // steps stays below 4 GiB per stream: 16 x 2^28 x 16 B would not, so the compact rows advance their BASE)
-    const float type_f = boarding ? 0.0f : 1.0f;
     const bool has_rew = reward != nullptr, has_af = agent_flags != nullptr, has_ef = env_flags != nullptr;
     const bool has_cmp = obs_compact != nullptr;
     typedef __attribute__((address_space(1))) char gchar;
@@ -302,7 +314,6 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
     gchar* b_af = (gchar*)agent_flags;
     gchar* b_ef = (gchar*)env_flags;
     gchar* b_cmp = (gchar*)obs_compact;
-    const uint32_t o_rew = idx * 8u, o_af = idx, o_ef = (uint32_t)env & 0x0FFFFFFFu, o_cmp = idx * 16u;
 
     unsigned long long acur = 0;
     {
@@ -378,12 +389,13 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
             wl[s & 1].slot[lane] = me;
             lds_barrier();
         }
-        const uint64_t ndest_b = __builtin_amdgcn_ballot_w64((validbit & ~dest) != 0);
+        const uint32_t tind = (ilo >> (tsh + kCellTermShift)) & 1u;            // terminateds[id] as the cell says (ccx_kernels.h)
+        const uint64_t ndest_b = __builtin_amdgcn_ballot_w64((validbit & ~tind) != 0);
         uint32_t ndest_grp;
         if constexpr (GLOG == 6) ndest_grp = (uint32_t)ndest_b | (uint32_t)(ndest_b >> 32);
         else ndest_grp = (uint32_t)(ndest_b >> gsh) & (uint32_t)full;
         const uint32_t all_dest = ndest_grp == 0u ? 1u : 0u;
-        const uint32_t term_out = term_all ? all_dest : dest;
+        const uint32_t term_out = term_all ? all_dest : tind;
         const uint32_t out2 = term_out | trunc2;
         tt |= out2;
         const uint32_t ef = all_dest | ((live_grp != 0u ? 2u : 0u) & ge_m);
@@ -396,12 +408,17 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
         if (valid) {
             if (has_rew) {
                 // rewards.py:44-182: the INTEGER is negated before the one f64 multiply (d == 0 gives +0.0)
-                const uint32_t cls = (ilo >> (tsh + 1u)) & 3u;
-                const int sd = (int)(int16_t)(uint16_t)(ihi >> tsh2);
-                double r = (double)sd * rF;
-                r = (cls == 1u) ? rA : r;
-                r = (cls == 2u) ? rB : r;
-                r = (cls == 3u) ? rC : r;
+                double r;
+                if (reward_table) {          // position-only user reward: one f64 per (type, cell)
+                    r = *(__attribute__((address_space(3))) const double*)(uintptr_t)((uint32_t)c8 + rt_add);
+                } else {
+                    const uint32_t cls = (ilo >> (tsh + 1u)) & 3u;
+                    const int sd = (int)(int16_t)(uint16_t)(ihi >> tsh2);
+                    r = (double)sd * rF;
+                    r = (cls == 1u) ? rA : r;
+                    r = (cls == 2u) ? rB : r;
+                    r = (cls == 3u) ? rC : r;
+                }
                 r = live ? r : 0.0;
                 *(__attribute__((address_space(1))) double*)(b_rew + o_rew) = r;
             }
@@ -473,11 +490,12 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-size_t step_lds_bytes(int glog, int ew, int N, int cells) {
+size_t step_lds_bytes(int glog, int ew, int N, int cells, bool reward_table) {
     auto up16 = [](size_t v) { return (v + 15u) & ~(size_t)15u; };
     const size_t msz = glog == 6 ? 8u : 4u;
     (void)N;
-    return up16((size_t)cells * 8u) + up16((size_t)ew * 2u * ((size_t)cells + 1u) * msz) + 2u * sizeof(WSlot);
+    return up16((size_t)cells * 8u) + (reward_table ? (size_t)cells * 16u : 0u) +
+           up16((size_t)ew * 2u * ((size_t)cells + 1u) * msz) + 2u * sizeof(WSlot);
 }
 
 template <int GLOG>
@@ -506,9 +524,10 @@ static hipError_t launch_step_g(const StepShape& ss, hipStream_t stream, const K
     double rA = p.reward_mode == CCX_K_REWARD_BINARY ? p.r_nogoal
                 : p.reward_mode == CCX_K_REWARD_CONSTANT_NEGATIVE ? p.r_pen : p.r_dest;
     double rB = p.r_door, rC = p.r_area, rF = p.r_f;
+    const double* reward_table = p.off_rtab ? p.reward_table : nullptr;
     void* args[] = {&st_base, &actions, &cell_info, &obs_table, &obs, &E, &shape, &grid_w, &max_steps,
                     &reward, &af, &ef, &cmp, &counters, &pool, &pool_size, &pool_stride, &env_offset_mod_pool,
-                    &dc, &div, &dl, &dr, &term_all, &auto_reset, &rA, &rB, &rC, &rF};
+                    &dc, &div, &dl, &dr, &term_all, &auto_reset, &rA, &rB, &rC, &rF, &reward_table};
     if (ss.lds_bytes > 60 * 1024) {
         hipError_t e = hipFuncSetAttribute(entry, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;

@@ -28,6 +28,10 @@ def _done(agent_id, env) -> bool:
 # ------------------------------------------------------------------------------------- rewards
 class RewardFunction(ABC):
     kernel_mode: int | None = None
+    # A user class whose value depends on NOTHING but the agent's own type and cell (and is ``None`` once the agent is
+    # terminated / truncated, like the built-in ones, rewards.py:64) may say so: the batch path then evaluates it once per
+    # (type, cell) on the host and runs it inside the kernels as a table (params.position_only_tables, ccx_set_reward_table).
+    position_only: bool = False
 
     def __init__(self, reward_config):
         self.reward_config = reward_config
@@ -105,6 +109,7 @@ REWARD_FUNCTIONS: dict[str, type[RewardFunction]] = {
 # ------------------------------------------------------------------------------------- termination
 class TerminatedFunction(ABC):
     kernel_mode: int | None = None
+    position_only: bool = False   # as for RewardFunction: terminateds[id] from the agent's own type and cell alone (ccx_set_terminated_table)
 
     def __init__(self, terminated_config):
         self.terminated_config = terminated_config

@@ -78,6 +78,8 @@ def lib() -> C.CDLL:
         L.ccxo_policy_actions.restype = None
         L.ccxo_policy_actions_eps.argtypes = [PP, C.c_int32, C.c_int32, C.c_int64] + [V] * 8
         L.ccxo_policy_actions_eps.restype = None
+        L.ccxo_set_user_tables.argtypes = [V, V, V, V]
+        L.ccxo_set_user_tables.restype = None
         L.ccxo_set_rng_seed.argtypes = [C.c_uint64]
         L.ccxo_set_rng_seed.restype = None
         L.ccxo_set_policy_epsilon.argtypes = [C.c_double]
@@ -166,6 +168,20 @@ class OracleBatch:
         self.counters = CcxCounters()
         self._mt: np.ndarray | None = None          # [E, 625] u32: one numpy-RandomState restatement per env
         self._mt_epsilon = 0.0
+        self._reward_tables = None                  # (boarding, exiting) f64 [H + 1, W + 1]: a position-only user reward
+        self._term_tables = None                    # (boarding, exiting) u8  [H + 1, W + 1]: a position-only user terminated value
+
+    def set_user_tables(self, reward=None, terminated=None) -> None:
+        """Tables of position-only user strategies (what ``ccx_set_reward_table`` / ``ccx_set_terminated_table`` install on the
+        GPU side); ``None`` = the built-in strategy."""
+        shape = (self.params.height + 1, self.params.width + 1)
+        self._reward_tables = None if reward is None else tuple(np.ascontiguousarray(t, np.float64).reshape(shape) for t in reward)
+        self._term_tables = None if terminated is None else tuple(
+            np.ascontiguousarray(np.asarray(t) != 0, np.uint8).reshape(shape) for t in terminated)
+
+    def _bind_tables(self) -> None:
+        r, t = self._reward_tables or (None, None), self._term_tables or (None, None)
+        lib().ccxo_set_user_tables(_p(r[0], np.float64), _p(r[1], np.float64), _p(t[0], np.uint8), _p(t[1], np.uint8))
 
     # -- state ------------------------------------------------------------------------------
     def set_state(self, x=None, y=None, active=None, terminated=None, truncated=None,
@@ -255,6 +271,7 @@ class OracleBatch:
         reward_ = np.empty((E, N), np.float64)
         af = np.empty((E, N), np.uint8)
         ef = np.empty((E,), np.uint8)
+        self._bind_tables()
         lib().ccxo_step(C.byref(self.params), E, _p(self.x, np.int32), _p(self.y, np.int32),
                         _p(self.active, np.uint8), _p(self.terminated, np.uint8),
                         _p(self.truncated, np.uint8), _p(self.step_count, np.int32),
@@ -277,6 +294,7 @@ class OracleBatch:
         af = np.empty((K, E, N), np.uint8) if want_traj else None
         ef = np.empty((K, E), np.uint8) if want_traj else None
         pool = self.pool
+        self._bind_tables()
         lib().ccxo_rollout(C.byref(self.params), E, self.env_offset, self.total_envs,
                            _p(self.x, np.int32), _p(self.y, np.int32), _p(self.active, np.uint8),
                            _p(self.terminated, np.uint8), _p(self.truncated, np.uint8),
@@ -301,6 +319,7 @@ class OracleBatch:
         ef = np.empty((K, E), np.uint8)
         pool = self.pool
         self._bind_stream()
+        self._bind_tables()
         lib().ccxo_rollout_policy(C.byref(self.params), self.POLICIES[policy], E, self.env_offset, self.total_envs,
                                   _p(self.x, np.int32), _p(self.y, np.int32), _p(self.active, np.uint8),
                                   _p(self.terminated, np.uint8), _p(self.truncated, np.uint8),

@@ -11,7 +11,8 @@ from collectivecrossing_amd import configs as C
 from collectivecrossing_amd.params import lower_config
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
-ALL_NPZ = sorted(p.stem for p in GOLDEN.glob("*.npz"))
+PLUGIN_NPZ = sorted(p.stem for p in GOLDEN.glob("g13_*.npz"))          # need tests/golden/custom_strategies.py registered first
+ALL_NPZ = sorted(p.stem for p in GOLDEN.glob("*.npz") if p.stem not in PLUGIN_NPZ)
 ROLLOUT_NPZ = [n for n in ALL_NPZ if n.startswith("g8_")]
 STEP_NPZ = [n for n in ALL_NPZ if not n.startswith("g8_")]
 
@@ -23,8 +24,12 @@ def config_from_dict(cfg: dict) -> C.CollectiveCrossingConfig:
     rc = dict(cfg.get("reward_config", {"reward_function": "default"}))
     tc = dict(cfg.get("terminated_config", {"terminated_function": "individual_at_destination"}))
     uc = dict(cfg.get("truncated_config", {"truncated_function": "max_steps"}))
-    kw["reward_config"] = C.get_reward_config(rc.pop("reward_function"), **rc)
-    kw["terminated_config"] = C.get_terminated_config(tc.pop("terminated_function"), **tc)
+    # (a name outside the config registry = a user-registered strategy class, g13: Custom*Config carries the name; the classes
+    # themselves are registered by the tests that load these fixtures, tests/golden/custom_strategies.py)
+    kw["reward_config"] = (C.get_reward_config(rc.pop("reward_function"), **rc) if rc["reward_function"] in C.REWARD_CONFIGS
+                           else C.CustomRewardConfig(**rc))
+    kw["terminated_config"] = (C.get_terminated_config(tc.pop("terminated_function"), **tc)
+                               if tc["terminated_function"] in C.TERMINATED_CONFIGS else C.CustomTerminatedConfig(**tc))
     kw["truncated_config"] = C.get_truncated_config(uc.pop("truncated_function"), **uc)
     if cfg.get("_relaxed"):
         kw.setdefault("observation_config", C.DefaultObservationConfig())
@@ -40,7 +45,7 @@ class Golden:
             self.a = {k: z[k] for k in z.files}
         self.cfg_dict = json.loads(str(self.a["config_json"]))
         self.config = config_from_dict(self.cfg_dict)
-        self.params = lower_config(self.config)
+        self.params = lower_config(self.config, allow_position_only=True)
         self.K, self.E, self.N = self.a["actions"].shape
         self.L = 6 + 4 * self.N
 

@@ -48,6 +48,41 @@ def make(reward_base, terminated_base, truncated_base):
     return {"reward": ArrivalBonusReward, "terminated": TramAreaTerminated, "truncated": PerTypeBudgetTruncated}
 
 
+def make_position_only(reward_base, terminated_base):
+    """Two plugins whose value depends on the agent's own type and cell ONLY (g13: what the batch path lowers to tables,
+    ccx_set_reward_table / ccx_set_terminated_table).  They say so with ``position_only = True`` -- an attribute the
+    reference ignores."""
+
+    class CellValueReward(reward_base):
+        position_only = True
+
+        def calculate_reward(self, agent_id, env):
+            a = env._agents[agent_id]
+            if a.terminated or a.truncated:                      # the built-in convention (rewards.py:64)
+                return None
+            x, y = int(a.position[0]), int(a.position[1])
+            v = 0.125 * x - 0.3 * y + (2.5 if env.is_in_tram_area(agent_id) else 0.0)
+            if env.has_agent_reached_destination(agent_id):
+                v += 7.0
+            return v if a.agent_type.value == "boarding" else -v
+
+    class TramAreaCellTerminated(terminated_base):
+        """Boarding agents are done inside the tram area (they stay active and keep blocking), exiting agents on their
+        destination row; a value on every step, like the built-in strategies."""
+        position_only = True
+
+        def calculate_terminated(self, agent_id, env):
+            a = env._agents[agent_id]
+            if a.agent_type.value == "boarding":
+                return bool(env.is_in_tram_area(agent_id))
+            return bool(env.has_agent_reached_destination(agent_id))
+
+    return {"reward": CellValueReward, "terminated": TramAreaCellTerminated}
+
+
+PO_NAMES = {"reward": "cell_value", "terminated": "tram_area_cell"}
+
+
 # the four recorded mixes: which of the three strategies is the user's (the rest stay built-in)
 MIXES = {"all": ("reward", "terminated", "truncated"), "reward": ("reward",), "terminated": ("terminated",),
          "truncated": ("truncated",)}

@@ -60,8 +60,13 @@ def build_ref_config(cfg: dict):
     rc = dict(cfg.get("reward_config", {"reward_function": "default"}))
     tc = dict(cfg.get("terminated_config", {"terminated_function": "individual_at_destination"}))
     uc = dict(cfg.get("truncated_config", {"truncated_function": "max_steps"}))
-    kw["reward_config"] = get_reward_config(rc.pop("reward_function"), **rc)
-    kw["terminated_config"] = get_terminated_config(tc.pop("terminated_function"), **tc)
+    from collectivecrossing.reward_configs import REWARD_CONFIGS, CustomRewardConfig
+    from collectivecrossing.terminated_configs import TERMINATED_CONFIGS, CustomTerminatedConfig
+    # (a name outside the config registry = a user-registered strategy class: the reference's Custom*Config carries the name)
+    kw["reward_config"] = (get_reward_config(rc.pop("reward_function"), **rc) if rc["reward_function"] in REWARD_CONFIGS
+                           else CustomRewardConfig(**rc))
+    kw["terminated_config"] = (get_terminated_config(tc.pop("terminated_function"), **tc)
+                               if tc["terminated_function"] in TERMINATED_CONFIGS else CustomTerminatedConfig(**tc))
     kw["truncated_config"] = get_truncated_config(uc.pop("truncated_function"), **uc)
     if cfg.get("_relaxed"):
         # reference-illegal agent counts (BASELINE config 5): bypass validation, SURVEY 8c
@@ -187,6 +192,17 @@ def cfg_c5(nb, ne, max_steps=500, **over):
              truncated_config=dict(truncated_function="max_steps", max_steps=max_steps))
     if nb + ne > 50:
         c["_relaxed"] = True
+    c.update(over)
+    return c
+
+
+def cfg_big(**over):
+    """The largest legal grid (configs.py:39-40: 100 x 100): its per-env occupancy tables exceed the LDS budget of the
+    kernels, which then resolve conflicts -- and, round 4, the in-kernel policies' `busy` bits -- through all-pairs compares."""
+    c = dict(width=100, height=100, division_y=50, tram_door_left=25, tram_door_right=35, tram_length=60,
+             num_boarding_agents=10, num_exiting_agents=10, exiting_destination_area_y=0,
+             boarding_destination_area_y=100,
+             truncated_config=dict(truncated_function="max_steps", max_steps=400))
     c.update(over)
     return c
 
@@ -467,6 +483,25 @@ def run_custom_strategies():
     print(f"wrote {f.name}: {len(out)} strategy mixes x 3 episodes x 24 steps, {f.stat().st_size / 1024:.0f} KiB")
 
 
+def run_position_only():
+    """g13_position_only_*: user-registered reward / terminated classes that depend on the agent's own type and cell only
+    (custom_strategies.make_position_only), registered with the imported reference and recorded in the array contract --
+    what collectivecrossing_amd lowers to ccx_set_reward_table / ccx_set_terminated_table."""
+    import custom_strategies as cs
+    from collectivecrossing import rewards, terminateds
+
+    plugins = cs.make_position_only(rewards.RewardFunction, terminateds.TerminatedFunction)
+    rewards.REWARD_FUNCTIONS[cs.PO_NAMES["reward"]] = plugins["reward"]
+    terminateds.TERMINATED_FUNCTIONS[cs.PO_NAMES["terminated"]] = plugins["terminated"]
+    both = dict(reward_config=dict(reward_function=cs.PO_NAMES["reward"]),
+                terminated_config=dict(terminated_function=cs.PO_NAMES["terminated"]),
+                truncated_config=dict(truncated_function="max_steps", max_steps=40))
+    run_random("g13_position_only_both", cfg_c1(**both), seeds=range(1300, 1308), K=60, shuffle=True, p_absent=0.1)
+    run_random("g13_position_only_reward", cfg_c1(reward_config=both["reward_config"], truncated_config=both["truncated_config"]),
+               seeds=range(1310, 1314), K=60)
+    run_random("g13_position_only_terminated_c3", cfg_c3(terminated_config=both["terminated_config"]), seeds=range(1320, 1322), K=50)
+
+
 ONLY = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
 
 
@@ -491,6 +526,11 @@ def main() -> int:
 
     if not ONLY or any("g12_custom_strategies".startswith(p) for p in ONLY):
         run_custom_strategies()
+    if not ONLY or any("g13_position_only".startswith(p) or p.startswith("g13") for p in ONLY):
+        run_position_only()
+    # G14: policies on a grid without LDS occupancy tables (100 x 100)
+    run_greedy("g14_greedy_100x100", cfg_big(), seeds=range(1400, 1402), K=230)
+    run_greedy("g14_waiting_100x100", cfg_big(num_boarding_agents=6, num_exiting_agents=5), seeds=range(1410, 1411), K=200, policy="waiting")
     # G1 / G2: BASELINE config-1 geometry, random actions, identity and shuffled move order
     run_random("g1_c1_random", cfg_c1(), seeds=range(0, 24), K=110)
     run_random("g2_c1_shuffled_absent", cfg_c1(), seeds=range(100, 116), K=110, shuffle=True,

@@ -173,9 +173,8 @@ def test_stream_argument_checks(ccx):
 
 
 def test_stream_rollout_on_a_grid_without_occupancy_tables(oracle, ccx):
-    """The fused policy kernel needs the LDS occupancy tables and is refused on a 100 x 100 grid; the stepwise loop of the
-    MT19937 stream runs the stand-alone policy kernel + ccx_step and works on any shape -- against the oracle, with the
-    all-pairs conflict path under it."""
+    """A 100 x 100 grid has no LDS occupancy tables; the stepwise loop of the MT19937 stream runs the stand-alone policy
+    kernel + ccx_step and works on any shape -- against the oracle, with the all-pairs conflict path under it."""
     from collectivecrossing_amd import configs as C
     from collectivecrossing_amd._lib import CcxError
     from collectivecrossing_amd.params import lower_config
@@ -195,8 +194,8 @@ def test_stream_rollout_on_a_grid_without_occupancy_tables(oracle, ccx):
         ob.set_state(x=pos[..., 0], y=pos[..., 1])
         env.set_state(x=pos[..., 0], y=pos[..., 1])
         env.set_policy_epsilon(0.3)
-        with pytest.raises(CcxError, match="occupancy tables"):
-            env.rollout_greedy(2)                              # counter-based draws = the fused kernel: refused here
+        # (round 4: the fused kernel no longer needs the occupancy tables for its policies -- tests/test_gpu_large_grid_policy.py;
+        # this test keeps to the stepwise MT19937 loop on such a grid)
         ob.set_policy_stream_mt19937(42, 0.3)
         env.set_policy_stream("mt19937", 42)
         o_act, o_obs, o_rew, o_af, o_ef = ob.rollout_greedy(K, policy="greedy")

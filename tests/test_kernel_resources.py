@@ -122,6 +122,6 @@ def test_sgpr_spills_of_the_hot_instantiations(tmp_path):
     edge = {k: v[2] for k, v in occ.items() if re.search(r"ILi\dELb[01]ELi2ELb1ELb1E", k) and "v128" not in k}
     assert edge and max(edge.values()) <= 16, edge
     rest = {k: v[2] for k, v in occ.items() if "v128" in k}
-    assert max(rest.values()) <= 72, {k: v for k, v in rest.items() if v > 72}
+    assert max(rest.values()) <= 76, {k: v for k, v in rest.items() if v > 76}   # (round 4: + the user reward / terminated tables, which live in these instantiations only)
     c5 = {k: v[2] for k, v in occ.items() if re.search(r"v128ILi6ELb1ELi[12]ELb1ELb0E", k)}
     assert len(c5) == 2 and max(c5.values()) <= 44, c5
