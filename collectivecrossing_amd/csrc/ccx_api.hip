@@ -192,18 +192,19 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
     //     compact rows keep a second writer busy), single-agent envs never (one writer: +30-40 %);
     //   small batches (unpaced, full or half tiles): 3-4 writers split by role, as measured in round 3;
     //   large tiles (> 24 store iterations per step): 3;
-    //   small tiles (<= 12 iterations, C2): two writers split by role while 3 waves per tile fit one round (three when a
-    //     tile has <= 8 iterations: 3 agents, 8192 envs 0.38 vs 0.47 us); beyond one round THREE (two tiles per workgroup =
-    //     8 waves, two workgroups per CU) -- the single throttled writer of rounds 1-3 was within 2 % of it for 8 agents but
-    //     lost 20-100 % for 1-3 agents (N = 1, 65 536 envs: 2.40 vs 1.17 us) and 17 % for 12 agents at 32 768 envs, and TWO
-    //     writers are a cliff there (6-wave workgroups: +35-80 %);
+    //   small tiles (<= 12 iterations): with <= 8 iterations per tile (1-3 agents) THREE writers whatever the batch (3
+    //     agents, 8192 envs 0.38 vs 0.47 us with two; N = 1, 65 536 envs: 1.17 vs 2.40 us with the single throttled writer of
+    //     rounds 1-3); with 9-12 iterations (C2's class) two writers split by role while 3 waves per tile fit one round, beyond
+    //     that ONE throttled writer as before: the sweep's short launches put three within 2 % of it, but the bench's settled
+    //     launches do not (C2 geometry, secondary.workloads: 16 384 envs 0.881 vs 0.845 of the peak with three, 65 536 envs
+    //     0.818 vs 0.747).  TWO writers are a cliff in several rounds (6-wave workgroups: +35-80 %);
     //   tiles in between: 2, or 1 + four tiles per workgroup when that makes the batch fit one round (C3, below).
     const long long cap_waves = 16ll * h->num_cus;
     int writers = h->writers > 0 ? h->writers
                   : !rows ? (glog <= 1 ? 2 : glog <= 4 ? (tiles >= 1024 ? 1 : 2) : (tiles >= 16384 ? 1 : 2))
                   : small_batch ? (half_tiles || tiles <= 160 ? 4 : 3)
                   : n4 > 64 * 24 ? 3
-                  : small_tiles ? ((long long)tiles * 3 <= cap_waves ? (n4 <= 64 * 8 ? 3 : 2) : 3) : 2;
+                  : small_tiles ? (n4 <= 64 * 8 ? 3 : (long long)tiles * 3 <= cap_waves ? 2 : 1) : 2;
     if (writers > 7) writers = 7;
     // tiles per workgroup: two small tiles share one cell table / one CU slot (with the throttle:
     // 4.43e9 vs 4.23e9 env-steps/s on C2; 3 or 4 per workgroup leave CUs idle and lose 5-10 %)
@@ -550,15 +551,15 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     if (out.obs_compact && (reinterpret_cast<uintptr_t>(out.obs_compact) & 15u))
         return fail(CCX_EINVAL, "obs_compact buffer must be 16-byte aligned");
     CCX_HIP(hipSetDevice(h->device));
-    if (K <= ccx::kStepMaxK && actions && !order && policy == 0 && !actions_out && h->step_shape.ok && h->tun_step_kernel != 0) {
+    if (K <= ccx::kStepMaxK && actions && policy == 0 && !actions_out && h->step_shape.ok && h->tun_step_kernel != 0) {
         // the short-launch kernel (ccx_step.hip): CollectiveCrossingEnv.step itself, no pacing, no controller state
         if (h->check_inputs) {
-            hipError_t ce = ccx::launch_check_inputs(h->stream, actions, nullptr, (size_t)K * (size_t)h->E, h->N, h->input_errors);
+            hipError_t ce = ccx::launch_check_inputs(h->stream, actions, order, (size_t)K * (size_t)h->E, h->N, h->input_errors);
             if (ce != hipSuccess) return fail(CCX_EHIP, "input check kernel launch failed: %s", hipGetErrorString(ce));
         }
         int rc = begin_timed(h);
         if (rc) return rc;
-        hipError_t e = ccx::launch_step(h->step_shape, h->stream, h->kp, h->st_slab, h->cell_info, actions, K, auto_reset,
+        hipError_t e = ccx::launch_step(h->step_shape, h->stream, h->kp, h->st_slab, h->cell_info, actions, order, K, auto_reset,
                                         h->pool, out, h->counters);
         if (e != hipSuccess) return fail(CCX_EHIP, "step kernel launch failed: %s", hipGetErrorString(e));
         return end_timed(h);

@@ -214,7 +214,7 @@ struct StepShape {
 constexpr int kStepMaxK = 16;   // env-steps per launch of the short-launch kernel (one burst of action loads)
 size_t step_lds_bytes(int glog, int ew, int N, int cells, bool reward_table);
 hipError_t launch_step(const StepShape& ss, hipStream_t stream, const KParams& p, uint8_t* st_base,
-                       const unsigned long long* cell_info, const uint8_t* actions, int K, int auto_reset,
+                       const unsigned long long* cell_info, const uint8_t* actions, const uint8_t* order, int K, int auto_reset,
                        const uint8_t* pool, const KOut& out, unsigned long long* counters);
 
 hipError_t launch_rollout(const LaunchShape& ls, hipStream_t stream, const KParams& p,

@@ -19,7 +19,7 @@
 //   * state write-back behind the last hand-off: everything drains together.
 // Tiles are smaller than the rollout's (a short launch is bound by latency, not by issue).
 //
-// Scope: actions from a tensor (no move order, no in-kernel policy), K <= 16 (one burst of action loads), LDS
+// Scope: actions from a tensor with or without a move order (no in-kernel policy), K <= 16 (one burst of action loads), LDS
 // occupancy tables (grids whose tables do not fit take the rollout kernel: ccx_api.hip decides).  Auto-reset from the
 // pool is supported (ccx_rollout with few steps).
 // The first 14 argument dwords (state slab, actions, both tables, obs, E, shape words, max_steps) are preloaded into SGPRs
@@ -63,7 +63,8 @@ __device__ __forceinline__ void step_store_obs(v2f v, const char* base, uint32_t
 template <int GLOG> struct RowBatch { static constexpr int value = GLOG <= 3 ? 8 : 16; };
 
 // K1: the launch is ONE env-step (ccx_step): one action load per lane instead of a burst of sixteen
-template <int GLOG, bool PAIR, bool K1>
+// ORD: the caller passed a move order (collectivecrossing.py:197: agents move in the order of `action_dict`)
+template <int GLOG, bool PAIR, bool K1, bool ORD>
 __global__ void __launch_bounds__(512)
 step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab layout
             const uint8_t* __restrict__ actions,                // u8 [K][E][N]
@@ -80,7 +81,8 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
             const uint32_t env_offset_mod_pool, const int dc, const int div, const int dl, const int dr,
             const int term_all, const int auto_reset,
             const double rA, const double rB, const double rC, const double rF,
-            const double* __restrict__ reward_table) {                 // user reward table f64 [2][cells] or null
+            const double* __restrict__ reward_table,                   // user reward table f64 [2][cells] or null
+            const uint8_t* __restrict__ order) {                       // u8 [K][E][N]: slot of the agent that moves k-th, or null
     using mask_t = typename GroupMask<GLOG>::type;
     constexpr int G = 1 << GLOG;
     constexpr uint32_t msz = sizeof(mask_t);
@@ -105,6 +107,7 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
     const uint32_t off_occ = off_rtab + (reward_table ? cells * 16u : 0u);
     const uint32_t occ_bytes = up16((uint32_t)EW * 2u * (cells + 1u) * msz);
     const uint32_t off_ws = off_occ + occ_bytes;
+    const uint32_t off_xch = off_ws + 2u * (uint32_t)sizeof(WSlot);          // 64 words: move-order exchange (ORD)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     int envs_here = E - env0;
     envs_here = envs_here < 0 ? 0 : (envs_here > EW ? EW : envs_here);
@@ -180,6 +183,7 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
     CCX_ST(0);
     CCX_ST_CLK0();
     const int g = lane >> GLOG, i = lane & (G - 1);
+    const int gbase = g << GLOG;
     const int env = env0 + g;
     const bool valid_env = (g < EW) && (env < E);
     const bool valid = valid_env && (i < N);
@@ -211,6 +215,24 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
             araw[d] = (uint32_t)actions[off];
             const uint32_t nx = off + EN;
             off = nx < lim ? nx : lim;
+        }
+    }
+    // move order: one byte per step and lane, packed 8 bits per step like the actions (16 steps = two 64-bit words)
+    unsigned long long ord_lo = 0, ord_hi = 0;
+    if constexpr (ORD) {
+        uint32_t oraw[kActBatch];
+        uint32_t off = idx_ld;
+        const uint32_t lim = idx_ld + (uint32_t)(K - 1) * EN;
+#pragma unroll
+        for (int d = 0; d < (K1 ? 1 : kActBatch); ++d) {
+            oraw[d] = (uint32_t)order[off];
+            const uint32_t nx = off + EN;
+            off = nx < lim ? nx : lim;
+        }
+#pragma unroll
+        for (int d = 0; d < (K1 ? 1 : kActBatch); ++d) {
+            if (d < 8) ord_lo |= (unsigned long long)(oraw[d] & 0xFFu) << (8 * d);
+            else ord_hi |= (unsigned long long)(oraw[d] & 0xFFu) << (8 * (d - 8));
         }
     }
     // the first chunks of the cell table travel with the state (small grids need nothing more)
@@ -336,13 +358,31 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
         const int np8 = c8 + (int)(int16_t)(uint16_t)(lut64 >> ((a & 3u) << 4));     // (wait / absent: any neighbour, never entered -- its legality bit 4 is 0)
         const uint32_t ok = (ilo >> a) & act;
         const uint32_t nok = ok ^ 1u;
-        // ---- 2. conflict masks from the occupancy / proposal tables (:536-541 in O(1) per agent)
+        // ---- move rank of this agent (dict order of action_dict, collectivecrossing.py:197); identity without ORD
+        int rank = i;
+        uint32_t src_lane = (uint32_t)lane;            // the lane whose agent has move rank i (= my lane index in the group)
+        mask_t my_rbit = mybit, lo_r = lo_m, later_r = later_m;
+        if constexpr (ORD) {
+            const uint32_t o_cur = valid ? (uint32_t)(ord_lo & 0xFFu) : (uint32_t)i;    // slot of the agent that moves i-th
+            ord_lo = (ord_lo >> 8) | (ord_hi << 56);
+            ord_hi >>= 8;
+            uint32_t* xch = reinterpret_cast<uint32_t*>(smem + off_xch);
+            xch[gbase + (int)(o_cur & (uint32_t)(G - 1))] = (uint32_t)i;
+            wave_lds_sync();
+            rank = (int)xch[lane];
+            wave_lds_sync();
+            src_lane = (uint32_t)gbase + (o_cur & (uint32_t)(G - 1));
+            my_rbit = mask_t(1) << rank;
+            lo_r = low_mask<mask_t>(rank);
+            later_r = ~lo_r & ~my_rbit;
+        }
+        // ---- 2. conflict masks from the occupancy / proposal tables (:536-541 in O(1) per agent), bits = move ranks
         const uint32_t ca = act ? tab_rel + ((uint32_t)c8 << TS) : dump_addr;
         const uint32_t ta = tab_rel + ((uint32_t)np8 << TS);
         const uint32_t qa = (ok ? ta : dump_addr) + msz;
         const unsigned long long pci = lds_cell(np8);
-        lds_or(ca, mybit);
-        lds_or(qa, mybit);
+        lds_or(ca, my_rbit);
+        lds_or(qa, my_rbit);
         wave_lds_sync();
         const mask2_t tt2 = *(__attribute__((address_space(3))) const mask2_t*)(uintptr_t)ta;
         wave_lds_sync();
@@ -353,8 +393,24 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
         uint32_t live_grp;
         if constexpr (GLOG == 6) live_grp = (uint32_t)live_b | (uint32_t)(live_b >> 32);
         else live_grp = (uint32_t)(live_b >> gsh) & (uint32_t)full;
-        const mask_t Cm = tt2.x & lo_m, Pm = tt2.y & lo_m;
-        const mask_t H = (tt2.x & later_m) | (mask_t)nok;
+        mask_t Cm = tt2.x & lo_r, Pm = tt2.y & lo_r;
+        mask_t H = (tt2.x & later_r) | (mask_t)nok;
+        if constexpr (ORD) {
+            // the fixed point below runs with lane = move rank: lane i takes over the masks of the agent that moves i-th
+            // (three cross-lane reads), and every agent finds its own verdict at bit `rank` of the final ballot
+            auto pull = [&](mask_t v) -> mask_t {
+                if constexpr (GLOG == 6) {
+                    const uint32_t lo32 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(uint32_t)v);
+                    const uint32_t hi32 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(uint32_t)(v >> 32));
+                    return (mask_t)lo32 | ((mask_t)hi32 << 32);
+                } else {
+                    return (mask_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(uint32_t)v);
+                }
+            };
+            Cm = pull(Cm);
+            Pm = pull(Pm);
+            H = pull(H);
+        }
         // ---- 3. ballot fixed point over "who moved" (ccx_rollout_body.inc, step 3)
         const uint64_t b0 = __builtin_amdgcn_ballot_w64((H | Cm) == 0);
         const mask_t M0 = group_raw(b0);
@@ -373,6 +429,7 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
                 b = b2;
             }
         }
+        if constexpr (ORD) mv_lane = ((group_raw(b) >> rank) & mask_t(1)) != 0;    // (the ballot is rank-indexed)
         if (mv_lane) {  // :408
             c8 = np8;
             ilo = (uint32_t)pci;
@@ -495,18 +552,22 @@ size_t step_lds_bytes(int glog, int ew, int N, int cells, bool reward_table) {
     const size_t msz = glog == 6 ? 8u : 4u;
     (void)N;
     return up16((size_t)cells * 8u) + (reward_table ? (size_t)cells * 16u : 0u) +
-           up16((size_t)ew * 2u * ((size_t)cells + 1u) * msz) + 2u * sizeof(WSlot);
+           up16((size_t)ew * 2u * ((size_t)cells + 1u) * msz) + 2u * sizeof(WSlot) + 256u /* move-order exchange */;
 }
 
 template <int GLOG>
 static hipError_t launch_step_g(const StepShape& ss, hipStream_t stream, const KParams& p, uint8_t* st_base,
-                                const unsigned long long* cell_info, const uint8_t* actions, int K, int auto_reset,
-                                const uint8_t* pool, const KOut& out, unsigned long long* counters) {
+                                const unsigned long long* cell_info, const uint8_t* actions, const uint8_t* order, int K,
+                                int auto_reset, const uint8_t* pool, const KOut& out, unsigned long long* counters) {
     const bool pair = (p.N % 2) == 0;
-    const void* entry = K == 1 ? (pair ? reinterpret_cast<const void*>(&step_kernel<GLOG, true, true>)
-                                       : reinterpret_cast<const void*>(&step_kernel<GLOG, false, true>))
-                               : (pair ? reinterpret_cast<const void*>(&step_kernel<GLOG, true, false>)
-                                       : reinterpret_cast<const void*>(&step_kernel<GLOG, false, false>));
+    auto pick = [&](auto ord_c) -> const void* {
+        constexpr bool ORD = decltype(ord_c)::value;
+        return K == 1 ? (pair ? reinterpret_cast<const void*>(&step_kernel<GLOG, true, true, ORD>)
+                              : reinterpret_cast<const void*>(&step_kernel<GLOG, false, true, ORD>))
+                      : (pair ? reinterpret_cast<const void*>(&step_kernel<GLOG, true, false, ORD>)
+                              : reinterpret_cast<const void*>(&step_kernel<GLOG, false, false, ORD>));
+    };
+    const void* entry = order ? pick(std::true_type{}) : pick(std::false_type{});
     int E = p.E;
     const int row_waves = out.obs ? ss.row_waves : 0;
     uint32_t shape = (uint32_t)p.N | ((uint32_t)p.Nb << 8) | ((uint32_t)ss.envs_per_wave << 16) | ((uint32_t)K << 24);
@@ -527,7 +588,7 @@ static hipError_t launch_step_g(const StepShape& ss, hipStream_t stream, const K
     const double* reward_table = p.off_rtab ? p.reward_table : nullptr;
     void* args[] = {&st_base, &actions, &cell_info, &obs_table, &obs, &E, &shape, &grid_w, &max_steps,
                     &reward, &af, &ef, &cmp, &counters, &pool, &pool_size, &pool_stride, &env_offset_mod_pool,
-                    &dc, &div, &dl, &dr, &term_all, &auto_reset, &rA, &rB, &rC, &rF, &reward_table};
+                    &dc, &div, &dl, &dr, &term_all, &auto_reset, &rA, &rB, &rC, &rF, &reward_table, &order};
     if (ss.lds_bytes > 60 * 1024) {
         hipError_t e = hipFuncSetAttribute(entry, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -536,16 +597,16 @@ static hipError_t launch_step_g(const StepShape& ss, hipStream_t stream, const K
 }
 
 hipError_t launch_step(const StepShape& ss, hipStream_t stream, const KParams& p, uint8_t* st_base,
-                       const unsigned long long* cell_info, const uint8_t* actions, int K, int auto_reset,
+                       const unsigned long long* cell_info, const uint8_t* actions, const uint8_t* order, int K, int auto_reset,
                        const uint8_t* pool, const KOut& out, unsigned long long* counters) {
     switch (ss.glog) {
-    case 0: return launch_step_g<0>(ss, stream, p, st_base, cell_info, actions, K, auto_reset, pool, out, counters);
-    case 1: return launch_step_g<1>(ss, stream, p, st_base, cell_info, actions, K, auto_reset, pool, out, counters);
-    case 2: return launch_step_g<2>(ss, stream, p, st_base, cell_info, actions, K, auto_reset, pool, out, counters);
-    case 3: return launch_step_g<3>(ss, stream, p, st_base, cell_info, actions, K, auto_reset, pool, out, counters);
-    case 4: return launch_step_g<4>(ss, stream, p, st_base, cell_info, actions, K, auto_reset, pool, out, counters);
-    case 5: return launch_step_g<5>(ss, stream, p, st_base, cell_info, actions, K, auto_reset, pool, out, counters);
-    case 6: return launch_step_g<6>(ss, stream, p, st_base, cell_info, actions, K, auto_reset, pool, out, counters);
+    case 0: return launch_step_g<0>(ss, stream, p, st_base, cell_info, actions, order, K, auto_reset, pool, out, counters);
+    case 1: return launch_step_g<1>(ss, stream, p, st_base, cell_info, actions, order, K, auto_reset, pool, out, counters);
+    case 2: return launch_step_g<2>(ss, stream, p, st_base, cell_info, actions, order, K, auto_reset, pool, out, counters);
+    case 3: return launch_step_g<3>(ss, stream, p, st_base, cell_info, actions, order, K, auto_reset, pool, out, counters);
+    case 4: return launch_step_g<4>(ss, stream, p, st_base, cell_info, actions, order, K, auto_reset, pool, out, counters);
+    case 5: return launch_step_g<5>(ss, stream, p, st_base, cell_info, actions, order, K, auto_reset, pool, out, counters);
+    case 6: return launch_step_g<6>(ss, stream, p, st_base, cell_info, actions, order, K, auto_reset, pool, out, counters);
     }
     return hipErrorInvalidValue;
 }

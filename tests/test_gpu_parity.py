@@ -515,8 +515,10 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
            mode=st.sampled_from(["actions", "actions", "greedy", "waiting", "random"]), compact=st.booleans(),
            writers=st.sampled_from([0, 0, 1, 2, 3, 4]), roles=st.sampled_from([-1, -1, 0, 1]),
            hand2=st.sampled_from([1, 1, 0, 2]), full_tiles=st.booleans(), eps=st.sampled_from([0.0, 0.0, 0.1, 0.5, 1.0]),
-           mt=st.sampled_from([False, False, True]), pair_rows=st.sampled_from([-1, -1, 0]))
-    def run(cfg, seed, E, K, mode, compact, writers, roles, hand2, full_tiles, eps, mt, pair_rows):
+           mt=st.sampled_from([False, False, True]), pair_rows=st.sampled_from([-1, -1, 0]),
+           step=st.sampled_from([(-1, 0, 0), (-1, 0, 0), (0, 0, 0), (1, 1, 0), (1, 2, 64), (1, 3, 16), (1, 5, 8), (1, 7, 0)]),
+           small_shape=st.sampled_from([1, 1, 0]), tables=st.sampled_from([0, 0, 0, 1, 2, 3]))
+    def run(cfg, seed, E, K, mode, compact, writers, roles, hand2, full_tiles, eps, mt, pair_rows, step, small_shape, tables):
         p = lower_config(cfg)
         N = p.num_boarding + p.num_exiting
         rng = np.random.default_rng(seed)
@@ -532,6 +534,20 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
             env.set_tunable("writer_roles", roles)
             env.set_tunable("hand2", hand2)
             env.set_tunable("pair_rows", pair_rows)
+            # round 4: the short-launch kernel (on / off, row waves, lanes), the no-rows launch shape, user tables
+            env.set_tunable("step_kernel", step[0])
+            env.set_tunable("step_rows", step[1])
+            env.set_tunable("step_lanes", step[2])
+            env.set_tunable("small_shape", small_shape)
+            if tables and (cfg.width + 3) * (cfg.height + 3) <= 1200:
+                shape = (cfg.height + 1, cfg.width + 1)
+                rew = (rng.normal(size=shape), rng.normal(size=shape)) if tables & 1 else None
+                term = ((rng.random(shape) < 0.15), (rng.random(shape) < 0.15)) if (tables & 2 and p.terminated_mode == 0) else None
+                if rew is not None:
+                    env.set_reward_table(*rew)
+                if term is not None:
+                    env.set_terminated_table(*term)
+                ob.set_user_tables(reward=rew, terminated=term)
             if full_tiles and mode in ("actions", "random"):   # (the scripted policies need the LDS occupancy tables)
                 try:
                     env.set_launch_shape(64, 0)

@@ -1,9 +1,9 @@
 """The short-launch kernel (csrc/ccx_step.hip): CollectiveCrossingEnv.step itself (collectivecrossing.py:161-261) for
 launches of 1..16 env-steps -- one workgroup per tile (a sim wave + row waves, one LDS barrier per step), no ring / pacing.
 
-ccx_step and short ccx_rollout calls take it by default (no move order, no in-kernel policy); the tunable `step_kernel`
-= 0 forces the rollout kernel.  Parity: (a) every reference-recorded step fixture whose dict order is the slot order,
-step by step, bit for bit; (b) the oracle, over launch lengths x batch sizes x agent counts (odd, 1, 50, 64) with
+ccx_step and short ccx_rollout calls take it by default (with or without a move order, no in-kernel policy); the tunable
+`step_kernel` = 0 forces the rollout kernel.  Parity: (a) EVERY reference-recorded step fixture step by step, bit for bit, with
+its recorded dict order (and, where that is the slot order, also without an order array); (b) the oracle, over launch lengths x batch sizes x agent counts (odd, 1, 50, 64) with
 auto-reset; (c) the rollout kernel on the same inputs (the two kernels are independent implementations of the step);
 (d) the step kernel is really the one that ran (its launch shape is reported, and a grid whose tables exceed the LDS
 falls back)."""
@@ -40,15 +40,16 @@ def test_enough_fixtures_reach_the_step_kernel():
     assert len(IDENTITY_NPZ) >= 20, IDENTITY_NPZ
 
 
-@pytest.mark.parametrize("name", IDENTITY_NPZ)
-def test_step_kernel_replays_the_reference_step_by_step(ccx, name):
-    """ccx_step without a move-order array = the short-launch kernel, against every reference-recorded step."""
+@pytest.mark.parametrize("name,with_order", [(n, True) for n in STEP_NPZ if not n.startswith("g14_")] + [(n, False) for n in IDENTITY_NPZ])
+def test_step_kernel_replays_the_reference_step_by_step(ccx, name, with_order):
+    """ccx_step = the short-launch kernel (with the recorded dict order as the move order, or without an order array where the
+    recording used the slot order), against every reference-recorded step."""
     g = Golden(name)
     env = ccx(g.config, g.E)
     assert env.step_shape()["ok"] == 1, "these grids fit the step kernel's LDS"
     env.set_state(**g.init_state())
     for s in range(g.K):
-        r = env.step(g["actions"][s])
+        r = env.step(g["actions"][s], g["order"][s] if with_order else None)
         assert_step_matches(g, s, _np(r.obs), _np(r.reward), _np(r.agent_flags), _np(r.env_flags), env.get_state())
     c = env.counters()
     assert c["env_steps"] == g.K * g.E and c["agent_steps"] == g.K * g.E * g.N
@@ -87,6 +88,8 @@ def test_short_launches_equal_the_oracle_and_the_rollout_kernel(oracle, ccx, cfg
     launches = 4
     actions = rng.integers(0, 6, size=(launches, K, E, N), dtype=np.uint8)
     actions[actions == 5] = 255                                   # some agents are absent from the action dict
+    # every other case drives the agents in shuffled dict orders (collectivecrossing.py:197)
+    orders = np.argsort(rng.random((launches, K, E, N)), axis=-1).astype(np.uint8) if (E + K) % 2 else None
     pool = build_reset_pool(cfg, 99, 61)
     ob = oracle.OracleBatch(params, E)
     ob.set_reset_pool(pool)
@@ -99,7 +102,7 @@ def test_short_launches_equal_the_oracle_and_the_rollout_kernel(oracle, ccx, cfg
             env.set_tunable("step_rows", wpb)
         env.set_reset_pool(pool)
         env.reset_from_pool()
-        res = [env.rollout(actions[j], auto_reset=True) for j in range(launches)]
+        res = [env.rollout(actions[j], None if orders is None else orders[j], auto_reset=True) for j in range(launches)]
         outs[step_kernel] = ([(_np(r.obs).view(np.uint32), _np(r.reward).view(np.uint64), _np(r.agent_flags), _np(r.env_flags))
                               for r in res], env.get_state(), env.counters())
         if step_kernel:
@@ -108,7 +111,7 @@ def test_short_launches_equal_the_oracle_and_the_rollout_kernel(oracle, ccx, cfg
         env.close()
         torch.cuda.empty_cache()
     for j in range(launches):
-        o_obs, o_rew, o_af, o_ef = ob.rollout(actions[j], auto_reset=True)
+        o_obs, o_rew, o_af, o_ef = ob.rollout(actions[j], None if orders is None else orders[j], auto_reset=True)
         for which in (1, 0):
             obs, rew, af, ef = outs[which][0][j]
             tag = f"launch {j} step_kernel={which}"
