@@ -202,7 +202,8 @@ def traffic_from_profiles(workload: str, E: int, N: int, chunk: int):
     """HBM bytes per launch from the PMC passes of an EARLIER rocprofv3 run of this same command
     (profiles/collect*.sh; counters cannot be collected inside a plain bench run).  Replayed from the
     tracked file, never measured here -- hence not `roofline.traffic`."""
-    names = ([f"r03_{workload}_traffic.json", f"r02_{workload}_traffic.json"] + (["r01_traffic.json"] if workload == "c2" else []))
+    names = ([f"r04_{workload}_traffic.json", f"r03_{workload}_traffic.json", f"r02_{workload}_traffic.json"] +
+             (["r01_traffic.json"] if workload == "c2" else []))
     for name in names:
         f = ROOT / "profiles" / name
         try:

@@ -66,6 +66,22 @@ def test_bench_line_has_the_contract_fields_and_adds_up():
     assert 0.1 < sec["no_obs"]["us_per_env_step"] < 5 and 1 < sec["step_k1"]["us_per_step"] < 100
     assert 1 < sec["step_k1_graph"]["us_per_step"] < 100          # (the same launches without the host in the loop)
     assert sec["no_obs"]["us_per_env_step"] * 0.8 < sec["compact_obs"]["us_per_env_step"] < 5
+    # round 4: every workload / batch size / duration the builder quotes is in the driver's line
+    wl = {(w["workload"], w["envs"]): w for w in sec["workloads"]}
+    assert set(wl) == {("c3", 4096), ("c5_50", 1024), ("c5_64", 1024), ("c2", 1024), ("c2", 2048), ("c2", 16384), ("c2", 32768), ("c2", 65536)}
+    for key, w in wl.items():
+        assert "error" not in w, w
+        assert 0.2 < w["frac_wall"] <= w["frac"] * 1.001 < 1.0 and w["timed_launches"] == 10 and w["kernel_ms_per_launch"] > 0, key
+        assert w["frac"] == pytest.approx(w["bytes_per_launch"] / (w["kernel_ms_per_launch"] * 1e-3) / 1e9 / 8000.0, rel=1e-9)
+    assert wl[("c3", 4096)]["agents"] == 32 and wl[("c5_64", 1024)]["policy"] == "greedy" and wl[("c5_64", 1024)]["agents"] == 64
+    su = sec["sustained"]
+    assert su["seconds"] >= 2.0 and su["launches"] >= 1000 and 0.2 < su["frac_wall"] <= su["frac_kernel_mean"] * 1.001 < 1.0
+    assert len(su["buckets"]) >= 8 and all(b["ms_min"] <= b["ms_median"] <= b["ms_max"] for b in su["buckets"])
+    sh = sec["short_launches"]
+    assert {"k1", "k2", "k4", "k8", "k16", "k32", "k64"} <= set(sh) and "error" not in sh
+    assert sh["k1"]["us_per_launch"] < sh["k16"]["us_per_launch"] < sh["k64"]["us_per_launch"] and sh["k16"]["frac"] > sh["k1"]["frac"]
+    # the short-launch kernel is what serves K = 1 (ccx_step.hip): device-side latency of a captured step
+    assert sh["k1"]["us_per_launch"] < 5.5 and sec["step_k1_graph"]["us_per_step"] < 5.5
 
 
 def test_bench_with_a_pace_cache_says_so(tmp_path):
@@ -86,6 +102,9 @@ def test_bench_cpu_baseline_leg():
     b = d["cpu_baseline"]
     assert b["kind"] == "port" and b["unit"] == "env-steps/s" and b["cores"] >= 1 and b["value"] > 1e5
     assert "sample" in b and b["value"] > 0
+    # (round 4) the leg says how many cores the box has, how many this process may use and how many threads it ran
+    assert b["threads_used"] == b["cores"] <= b["cores_of_the_box"] and b["cores_in_affinity_mask"] >= b["cores"]
+    assert b["cgroup_cpu_quota"] is None or b["cgroup_cpu_quota"] > 0
 
 
 def test_bare_command_with_two_ranks_sharing_the_gpu():
