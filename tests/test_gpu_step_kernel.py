@@ -218,3 +218,33 @@ def test_a_graph_of_single_steps_replays_bit_exactly(oracle, ccx):
     np.testing.assert_array_equal(st["x"], ob.x)
     np.testing.assert_array_equal(st["step_count"], ob.step_count)
     env.close()
+
+
+def test_short_launches_of_a_shard_walk_the_pool_by_global_env_index(oracle, ccx):
+    """A shard of a larger batch (env_offset / total_envs, collectivecrossing_amd/sharding.py): restarts inside short launches take
+    the pool entry of the GLOBAL env index, so trajectories do not depend on the world size -- step kernel vs oracle."""
+    import bench
+    from collectivecrossing_amd.params import lower_config
+    from collectivecrossing_amd.reset import build_reset_pool
+    cfg = bench.c2_config(max_steps=7)
+    E, off, total, K = 500, 1500, 4000, 5
+    pool = build_reset_pool(cfg, 5, 97)
+    ob = oracle.OracleBatch(lower_config(cfg), E, env_offset=off, total_envs=total)
+    env = ccx(cfg, E, env_offset=off, total_envs=total)
+    assert env.step_shape()["ok"] == 1
+    for b in (ob, env):
+        b.set_reset_pool(pool)
+        b.reset_from_pool()
+    rng = np.random.default_rng(3)
+    for launch in range(6):
+        a = rng.integers(0, 5, size=(K, E, 8), dtype=np.uint8)
+        res = env.rollout(a, auto_reset=True)
+        o_obs, o_rew, o_af, o_ef = ob.rollout(a, auto_reset=True)
+        np.testing.assert_array_equal(_np(res.env_flags), o_ef)
+        np.testing.assert_array_equal(_np(res.agent_flags), o_af)
+        np.testing.assert_array_equal(_np(res.obs).view(np.uint32), o_obs.view(np.uint32))
+    st = env.get_state()
+    for k in ("x", "y", "episode", "step_count"):
+        np.testing.assert_array_equal(st[k], getattr(ob, k), err_msg=k)
+    assert env.counters() == ob.counters.as_dict() and ob.counters.episodes > 0
+    env.close()
