@@ -189,7 +189,10 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
     //   launches WITHOUT observation rows (rewards / flag bytes / compact rows: bound by the sim chain and by how many tiles
     //     are resident): two writers split by role, ONE from 1024 tiles on (8 agents, 16 384 envs: 0.55 vs 0.91 us per
     //     env-step with two; 32 agents, 32 768 envs: 4.1 vs 6.3) -- lane groups of 32 / 64 only from 16 384 tiles on (their
-    //     compact rows keep a second writer busy), single-agent envs never (one writer: +30-40 %);
+    //     compact rows keep a second writer busy), single-agent envs never (one writer: +30-40 %); with 257-512 tiles -- one
+    //     per two SIMDs, C2's 4096 envs -- FOUR writers in one-tile workgroups (the two spare waves only poll): every agent
+    //     count of the sweep is 4-6 % faster than with two (8 agents, 4096 envs: 0.319 vs 0.338 us per env-step;
+    //     profiles/scratch/calls/r04_call19.sh, r04_call21.sh);
     //   small batches (unpaced, full or half tiles): 3-4 writers split by role, as measured in round 3;
     //   large tiles (> 24 store iterations per step): 3;
     //   small tiles (<= 12 iterations): with <= 8 iterations per tile (1-3 agents) THREE writers whatever the batch (3
@@ -201,7 +204,8 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
     //   tiles in between: 2, or 1 + four tiles per workgroup when that makes the batch fit one round (C3, below).
     const long long cap_waves = 16ll * h->num_cus;
     int writers = h->writers > 0 ? h->writers
-                  : !rows ? (glog <= 1 ? 2 : glog <= 4 ? (tiles >= 1024 ? 1 : 2) : (tiles >= 16384 ? 1 : 2))
+                  : !rows ? ((tiles > 256 && tiles <= 512) ? 4   // one tile per two SIMDs: five-wave workgroups, one tile each (below)
+                             : glog <= 1 ? 2 : glog <= 4 ? (tiles >= 1024 ? 1 : 2) : (tiles >= 16384 ? 1 : 2))
                   : small_batch ? (half_tiles || tiles <= 160 ? 4 : 3)
                   : n4 > 64 * 24 ? 3
                   : small_tiles ? (n4 <= 64 * 8 ? 3 : (long long)tiles * 3 <= cap_waves ? 2 : 1) : 2;
@@ -209,7 +213,7 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
     // tiles per workgroup: two small tiles share one cell table / one CU slot (with the throttle:
     // 4.43e9 vs 4.23e9 env-steps/s on C2; 3 or 4 per workgroup leave CUs idle and lose 5-10 %)
     int tpb = h->waves_per_block > 0 ? h->waves_per_block
-              : small_batch ? 1 : (tiles > 8192 || (small_tiles && tiles >= 512)) ? 2 : 1;
+              : small_batch ? 1 : (!rows && writers == 4) ? 1 : (tiles > 8192 || (small_tiles && tiles >= 512)) ? 2 : 1;
     // One round beats two (round 2): a CU holds 16 wavefronts of this kernel (4 per SIMD at its ~100
     // VGPRs).  If the batch needs more than that with the writer count above but fits with ONE writer
     // wave per tile, and that writer's share stays <= 36 store iterations per step, every tile is

@@ -81,7 +81,7 @@ def main():
                 cands = []
                 lanes_set = [l for l in (G, 2 * G, 4 * G, 8 * G, 16 * G, 32 * G, 64 * G) if min(64, max(G, 8)) <= l <= 64]
                 for lanes in lanes_set:
-                    for writers in ((0, 1, 2, 3, 4) if mode == "rows" else (0, 1, 2)):
+                    for writers in (0, 1, 2, 3, 4):
                         try:
                             env.set_launch_shape(lanes, 0)
                             env.set_writers(writers)
