@@ -631,6 +631,7 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     ccx::KParams kp = small_launch ? h->kp_small : h->kp;
     kp.rng_lo = h->kp.rng_lo; kp.rng_hi = h->kp.rng_hi; kp.eps_thr = h->kp.eps_thr;
     kp.pace_slot = h->pace_slot;
+    kp.launch_flags = 0u;
     // launches the kernel will not pace hand steps to the writer waves through sequence words (ccx_kernels.h: one
     // definition of the launch modes for the host and the kernel)
     kp.hand_flags = ccx::launch_uses_flags(kp.pace_state != nullptr, writes_obs, K, kp.pace_min_k, h->tun_hand2) ? 1u : 0u;
@@ -649,8 +650,33 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     if (adaptive && capturing) kp.pace_adapt = 0u;
     int rc = begin_timed(h);
     if (rc) return rc;
-    hipError_t e = ccx::launch_rollout(shape, h->stream, kp, h->st, h->cell_info, actions,
-                                       order, K, auto_reset, h->pool, out, h->counters, policy, actions_out);
+    // A grid of more workgroups than the device holds is launched ROUND BY ROUND: one launch per `resident_blocks`
+    // workgroups, back to back on the stream.  In ONE launch the workgroups of the second round start as slots come free, each on
+    // a schedule of its own, and the chip's write front -- one narrow window per env-step while the tiles march in step --
+    // frays over several slabs.  A launch boundary between the rounds (~2 us against rounds of 100+ us) restarts every round in step.  The kernel sees
+    // its place in the grid through block_base (env indices, tile phases) and knows that it is one round (launch_flags: the pace of a partial last round); the
+    // controller's owner is tile 0 of the first launch and all rounds vote into the same slot, as in one launch.
+    // Only where the rows of the launch exceed the reach of the address-translation cache (~4 GB, profiles/r04_output_size.txt):
+    // below it the boundary costs 1-2 % (32 768 envs x 64 steps: 0.887 -> 0.873), beyond it the rounds in step win 3-5 %
+    // (65 536 x 64: 0.750 -> 0.785; the fewer slabs the chip writes at a time, the fewer pages it walks at a time).
+    const int resident = shape.resident_blocks;
+    const double rows_bytes = writes_obs ? (double)K * (double)h->E * h->N * (double)(6 + 4 * h->N) * 4.0 : 0.0;
+    const bool by_rounds = resident > 0 && shape.num_blocks > resident &&
+                           (h->tun_round_launches >= 2 || (h->tun_round_launches == 1 && rows_bytes > 3.5e9));
+    hipError_t e = hipSuccess;
+    if (by_rounds) {
+        ccx::LaunchShape round = shape;
+        kp.launch_flags |= ccx::CCX_K_LAUNCH_ROUND;
+        for (int b0 = 0; b0 < shape.num_blocks && e == hipSuccess; b0 += resident) {
+            round.num_blocks = std::min(resident, shape.num_blocks - b0);
+            kp.block_base = (uint32_t)b0;
+            e = ccx::launch_rollout(round, h->stream, kp, h->st, h->cell_info, actions,
+                                    order, K, auto_reset, h->pool, out, h->counters, policy, actions_out);
+        }
+    } else {
+        e = ccx::launch_rollout(shape, h->stream, kp, h->st, h->cell_info, actions,
+                                order, K, auto_reset, h->pool, out, h->counters, policy, actions_out);
+    }
     if (e != hipSuccess) return fail(CCX_EHIP, "rollout kernel launch failed: %s", hipGetErrorString(e));
     // the kernel collected the votes for the next pace in the other slot (same condition as in the kernel)
     if (adaptive && !capturing) h->pace_slot ^= 1u;
@@ -1289,6 +1315,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
         {"max_launch_steps", &h->tun_max_launch_steps, 0, 0x7FFFFFFF},
         {"pair_rows", &h->tun_pair_rows, -1, 1},
         {"small_shape", &h->tun_small_shape, 0, 1},
+        {"round_launches", &h->tun_round_launches, 0, 2},
         {"step_kernel", &h->tun_step_kernel, -1, 1},
         {"step_rows", &h->tun_step_rows, 0, 7},
         {"step_lanes", &h->tun_step_lanes, 0, 64},

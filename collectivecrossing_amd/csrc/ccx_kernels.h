@@ -85,6 +85,7 @@ __host__ __device__ inline bool launch_is_adaptive(bool handle_paces, bool handl
 __host__ __device__ inline bool launch_uses_flags(bool handle_paces, bool writes_obs, int K, uint32_t pace_min_k, int tunable) {
     return tunable >= 2 || (tunable == 1 && !launch_is_paced(handle_paces, writes_obs, K, pace_min_k));   // 0 = never, 1 = unpaced launches, 2 = always
 }
+enum : uint32_t { CCX_K_LAUNCH_ROUND = 1u };
 enum : uint32_t { CCX_K_EF_ALL_TERM = 1u, CCX_K_EF_ALL_TRUNC = 2u, CCX_K_EF_RESET = 4u };
 
 // kernel parameters (passed by value; lives in SGPRs / the kernarg segment)
@@ -132,6 +133,9 @@ struct KParams {
     const double* reward_table;
     uint32_t off_rtab;
     uint32_t user_tables;                // 1: a user reward / terminated table is set: launch the instantiations that are not PLAIN
+    // A grid of more workgroups than the device holds is launched ROUND BY ROUND (ccx_api.hip: run_rollout): this launch
+    // carries workgroups block_base .. block_base + gridDim.x - 1 of the grid (launch_flags bit 0: it is one round of a larger grid).
+    uint32_t block_base, launch_flags;
 #ifdef CCX_LAG_TRACE
     int* lag_trace;                      // diagnostic build: [16 traced tiles][4096 steps] lag behind the schedule, 10-ns ticks
     int lag_every;                       // every lag_every-th tile is traced

@@ -73,7 +73,7 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
             float* __restrict__ obs,                            // f32 [K][E][N][L] or null
             const int E,
             const uint32_t shape,                               // N | Nb << 8 | EW << 16 | K << 24
-            const uint32_t grid,                                // cells of the padded grid | (W + 3) << 16 | row waves per tile << 24
+            const uint32_t grid,                                // cells of the padded grid | (W + 3) << 16 | row waves per tile << 24 | (reward table ? 1 : 0) << 31
             const int max_steps,
             double* __restrict__ reward, uint8_t* __restrict__ agent_flags, uint8_t* __restrict__ env_flags,
             float* __restrict__ obs_compact, unsigned long long* __restrict__ counters,
@@ -96,7 +96,8 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
     const int K = K1 ? 1 : (int)(shape >> 24);
     const uint32_t cells = grid & 0xFFFFu;
     const int Wp = (int)((grid >> 16) & 0xFFu);
-    const int RW = (int)(grid >> 24);                                          // row waves of this launch (0: no observation rows)
+    const int RW = (int)((grid >> 24) & 0x7Fu);                                // row waves of this launch (0: no observation rows)
+    const bool has_rtab = (grid >> 31) != 0u;        // (a preloaded bit: the LDS layout must not wait for the pointer's scalar load)
     const int tile = (int)blockIdx.x;
     const int env0 = tile * EW;
     const int L = 6 + 4 * N;
@@ -104,7 +105,7 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
     // LDS of the workgroup: [cell table][occupancy / proposal tables][two staging slots (float4 per lane + row constants)]
     auto up16 = [](uint32_t v) { return (v + 15u) & ~15u; };
     const uint32_t off_rtab = up16(cells * 8u);                               // (the region exists only with a user reward table)
-    const uint32_t off_occ = off_rtab + (reward_table ? cells * 16u : 0u);
+    const uint32_t off_occ = off_rtab + (has_rtab ? cells * 16u : 0u);
     const uint32_t occ_bytes = up16((uint32_t)EW * 2u * (cells + 1u) * msz);
     const uint32_t off_ws = off_occ + occ_bytes;
     const uint32_t off_xch = off_ws + 2u * (uint32_t)sizeof(WSlot);          // 64 words: move-order exchange (ORD)
@@ -139,6 +140,10 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
                 const uint32_t q = (uint32_t)lane + 64u * (it0 + j) - lead0;
                 tw0[j] = table_word(q < n4 ? q : 0u);
             }
+            // (pinned: left alone the compiler sinks these loads below the barrier, to their use -- a memory round trip on the
+            //  row wave's path AFTER its release instead of beside the sim wave's work)
+#pragma unroll
+            for (int j = 0; j < kRowBatch; ++j) tw0[j] = in_vgpr(tw0[j]);
         }
         for (int s = 0; s < K; ++s) {
             const uint32_t lead = (uint32_t)(reinterpret_cast<uintptr_t>(obs_s) & 127u) / vbytes;
@@ -286,7 +291,7 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
         if (cw < cells) cinfo[cw] = c_first[r];
     }
     for (uint32_t cw = (uint32_t)lane + 64u * kCellFirst; cw < cells; cw += 64u) cinfo[cw] = cell_info[cw];
-    if (reward_table) {
+    if (has_rtab) {
         double* rt = reinterpret_cast<double*>(smem + off_rtab);
         for (uint32_t t = (uint32_t)lane; t < 2u * cells; t += 64u) rt[t] = reward_table[t];
     }
@@ -466,7 +471,7 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
             if (has_rew) {
                 // rewards.py:44-182: the INTEGER is negated before the one f64 multiply (d == 0 gives +0.0)
                 double r;
-                if (reward_table) {          // position-only user reward: one f64 per (type, cell)
+                if (has_rtab) {          // position-only user reward: one f64 per (type, cell)
                     r = *(__attribute__((address_space(3))) const double*)(uintptr_t)((uint32_t)c8 + rt_add);
                 } else {
                     const uint32_t cls = (ilo >> (tsh + 1u)) & 3u;
@@ -572,7 +577,8 @@ static hipError_t launch_step_g(const StepShape& ss, hipStream_t stream, const K
     const int row_waves = out.obs ? ss.row_waves : 0;
     uint32_t shape = (uint32_t)p.N | ((uint32_t)p.Nb << 8) | ((uint32_t)ss.envs_per_wave << 16) | ((uint32_t)K << 24);
     const uint32_t cells = (uint32_t)((p.W + 3) * (p.H + 3));
-    uint32_t grid_w = cells | ((uint32_t)(p.W + 3) << 16) | ((uint32_t)row_waves << 24);
+    const double* reward_table = p.off_rtab ? p.reward_table : nullptr;
+    uint32_t grid_w = cells | ((uint32_t)(p.W + 3) << 16) | ((uint32_t)row_waves << 24) | (reward_table ? 0x80000000u : 0u);
     int max_steps = p.max_steps;
     const uint16_t* obs_table = p.obs_table;
     float* obs = out.obs;
@@ -585,7 +591,6 @@ static hipError_t launch_step_g(const StepShape& ss, hipStream_t stream, const K
     double rA = p.reward_mode == CCX_K_REWARD_BINARY ? p.r_nogoal
                 : p.reward_mode == CCX_K_REWARD_CONSTANT_NEGATIVE ? p.r_pen : p.r_dest;
     double rB = p.r_door, rC = p.r_area, rF = p.r_f;
-    const double* reward_table = p.off_rtab ? p.reward_table : nullptr;
     void* args[] = {&st_base, &actions, &cell_info, &obs_table, &obs, &E, &shape, &grid_w, &max_steps,
                     &reward, &af, &ef, &cmp, &counters, &pool, &pool_size, &pool_stride, &env_offset_mod_pool,
                     &dc, &div, &dl, &dr, &term_all, &auto_reset, &rA, &rB, &rC, &rF, &reward_table, &order};

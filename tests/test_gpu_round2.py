@@ -744,3 +744,45 @@ def test_cut_rollouts_of_an_odd_number_of_agent_slots_stay_aligned(ccx, oracle):
         env.set_tunable("max_launch_steps", 7)
 
     _against_oracle(oracle, ccx, g, E, K, seed=11, setup=setup)
+
+
+# ---- round 4: grids of several rounds -- partial last rounds and round-by-round launches ------------------------------
+def test_a_partial_last_round_does_not_drive_the_common_pace_up(ccx):
+    """The tiles of a partial last round run on a schedule scaled to their number, which their own step chain may not be
+    able to follow (20 000 envs of C2: 226 of 1250 workgroups in the second round).  They voted 'late' all the same and the
+    controller raised the COMMON pace until they were on time: 0.67 of the peak for 20 000 envs, 0.27 for 100 003 (pace
+    3.5 x its value; profiles/r04_multi_round.txt).  Such tiles no longer vote: the pace of a ragged batch settles where the
+    pace of the full batch next to it does."""
+    import torch
+    cfg = _shape_config("c2")
+    paces = {}
+    for E in (16384, 20000):
+        env = ccx(cfg, E)
+        try:
+            env.make_reset_pool(0, 512)
+            env.reset_from_pool()
+            K = 64
+            acts = torch.randint(0, 5, (K, E, env.num_agents), dtype=torch.uint8, device=env.device)
+            traj = env.alloc_rollout(K)
+            for _ in range(60):
+                env.rollout(acts, auto_reset=True, out=traj)
+            torch.cuda.synchronize()
+            shape = env.launch_shape()
+            paces[E] = env.step_pace_ns()
+            if E == 20000:
+                assert shape["num_blocks"] > shape["resident_blocks"] > 0 and shape["num_blocks"] % shape["resident_blocks"] != 0
+        finally:
+            env.close()
+    assert paces[16384] > 0 and paces[20000] < 1.15 * paces[16384], paces
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_round_by_round_launches_equal_the_oracle(oracle, ccx, mode):
+    """A grid of more workgroups than the device holds is launched one round per launch when its rows exceed the reach of
+    the translation cache (ccx_api.hip: run_rollout, KParams::block_base / launch_flags; tunable round_launches: 0 = one
+    launch, 2 = always by rounds): 6001 envs of the C3 geometry in 3001 tiles -- ragged last tile, partial last round -- are
+    bit-equal to the oracle either way, and the counters add up over the rounds."""
+    g = Golden("g3_c3_dense_simple_distance")
+    c, shape, _, _ = _against_oracle(oracle, ccx, g, E=6001, K=17, seed=35, order=False,
+                                     setup=lambda env: env.set_tunable("round_launches", mode))
+    assert shape["num_blocks"] > shape["resident_blocks"] > 0
