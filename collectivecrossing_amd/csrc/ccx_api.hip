@@ -197,8 +197,11 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
     //   large tiles (> 24 store iterations per step): 3;
     //   small tiles (<= 12 iterations): with <= 8 iterations per tile (1-3 agents) THREE writers whatever the batch (3
     //     agents, 8192 envs 0.38 vs 0.47 us with two; N = 1, 65 536 envs: 1.17 vs 2.40 us with the single throttled writer of
-    //     rounds 1-3); with 9-12 iterations (C2's class) two writers split by role while 3 waves per tile fit one round, beyond
-    //     that ONE throttled writer as before: the sweep's short launches put three within 2 % of it, but the bench's settled
+    //     rounds 1-3); with 9-12 iterations (C2's class) two writers split by role up to four tiles per CU (two six-wave
+    //     workgroups; the rule used to read "while 3 waves per tile fit one round", i.e. up to 1365 tiles, and every batch of
+    //     8193 .. 10 920 envs of C2 ran at 0.49 of the peak with a third workgroup on some CUs: profiles/r04_ragged_c2.txt) --
+    //     in pairs up to two tiles per CU (C2's 4096 envs), THREE in one-tile workgroups from there to four (5000 .. 8192 envs:
+    //     0.92-0.94 vs 0.89-0.93 with two, two runs of that table) --, beyond that ONE throttled writer as before: the sweep's short launches put three within 2 % of it, but the bench's settled
     //     launches do not (C2 geometry, secondary.workloads: 16 384 envs 0.881 vs 0.845 of the peak with three, 65 536 envs
     //     0.818 vs 0.747).  TWO writers are a cliff in several rounds (6-wave workgroups: +35-80 %);
     //   tiles in between: 2, or 1 + four tiles per workgroup when that makes the batch fit one round (C3, below).
@@ -208,12 +211,15 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
                              : glog <= 1 ? 2 : glog <= 4 ? (tiles >= 1024 ? 1 : 2) : (tiles >= 16384 ? 1 : 2))
                   : small_batch ? (half_tiles || tiles <= 160 ? 4 : 3)
                   : n4 > 64 * 24 ? 3
-                  : small_tiles ? (n4 <= 64 * 8 ? 3 : (long long)tiles * 3 <= cap_waves ? 2 : 1) : 2;
+                  : small_tiles ? (n4 <= 64 * 8 ? 3 : tiles <= 2 * h->num_cus ? 2 : tiles <= 4 * h->num_cus ? 3 : 1) : 2;
     if (writers > 7) writers = 7;
     // tiles per workgroup: two small tiles share one cell table / one CU slot (with the throttle:
     // 4.43e9 vs 4.23e9 env-steps/s on C2; 3 or 4 per workgroup leave CUs idle and lose 5-10 %)
     int tpb = h->waves_per_block > 0 ? h->waves_per_block
-              : small_batch ? 1 : (!rows && writers == 4) ? 1 : (tiles > 8192 || (small_tiles && tiles >= 512)) ? 2 : 1;
+              : small_batch ? 1 : (!rows && writers == 4) ? 1
+              : (rows && small_tiles && writers == 1 && tiles <= 8 * h->num_cus) ? 1   // (one round of two-wave workgroups: +1-3 % over pairs, 10 000 .. 16 384 envs of C2)
+              : (rows && small_tiles && n4 > 64 * 8 && writers == 3) ? 1
+              : (tiles > 8192 || (small_tiles && tiles >= 512)) ? 2 : 1;
     // One round beats two (round 2): a CU holds 16 wavefronts of this kernel (4 per SIMD at its ~100
     // VGPRs).  If the batch needs more than that with the writer count above but fits with ONE writer
     // wave per tile, and that writer's share stays <= 36 store iterations per step, every tile is

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 4, call 35: the six-wave cliff of 8193 .. 10 920 envs closed (two writers only up to four tiles per CU), one-tile workgroups for
+# one round of single-writer tiles: guards, round-2 tests, the ragged table again, the driver's bench command
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r04_c35
+mkdir -p $OUT
+cd $ROOT
+timeout -k 10 900 python3 -m pytest tests/test_gpu_shape_guard.py tests/test_gpu_round2.py -m gpu -q > $OUT/pytest.txt 2>&1; tail -4 $OUT/pytest.txt; grep -n "^FAILED\|^ERROR\|AssertionError: (" $OUT/pytest.txt | cut -c1-600 | head
+timeout -k 10 500 python3 profiles/scratch/ragged.py $OUT/ragged_c2.json c2 2>&1 | grep -v amdgpu | tee $OUT/ragged_c2.txt
+timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_flags.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
+python3 - <<PY
+import json
+d = json.loads(open("$OUT/bench_driver_flags.json").read().strip().splitlines()[-1])
+print("value", d["value"], "frac", d["roofline"]["frac"], "cold", d["cold"]["value"])
+s = d["secondary"]
+for w in s.get("workloads", []):
+    print(w.get("workload"), w.get("envs"), w.get("error") or (round(w["frac"],3), round(w["frac_wall"],3), round(w["kernel_ms_per_launch"],4), w["launch_shape"]["lanes_per_wave"], w["launch_shape"]["writers_per_tile"], w["launch_shape"]["waves_per_block"]))
+PY
