@@ -497,7 +497,7 @@ def measure_workload(torch, dev, name: str, envs: int, chunk: int, policy: str, 
 # (workload, envs per GPU or 0 = the workload's own, env-steps per launch, policy): BASELINE configs[2] and [4] (both agent
 # counts), and the C2 geometry from 1024 to 65 536 envs (small batches, several rounds of workgroups) -- VERDICT r3 item 2.
 # The large batches take fewer steps per launch so that their rows stay ~2.7 GB, the headline launch's size: the same launch
-# loses 5-8 % once its output passes ~4 GB, the reach of the address-translation cache (profiles/r04_output_size.txt)
+# loses 5-8 % once the memory it streams through passes ~4 GB (profiles/r04_output_size.txt)
 SECONDARY_WORKLOADS = [("c3", 0, 500, "random"), ("c5_50", 0, 500, "greedy"), ("c5_64", 0, 500, "greedy"),
                        ("c2", 1024, 500, "random"), ("c2", 2048, 500, "random"), ("c2", 16384, 64, "random"),
                        ("c2", 32768, 64, "random"), ("c2", 65536, 32, "random")]

@@ -665,9 +665,10 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     // frays over several slabs.  A launch boundary between the rounds (~2 us against rounds of 100+ us) restarts every round in step.  The kernel sees
     // its place in the grid through block_base (env indices, tile phases) and knows that it is one round (launch_flags: the pace of a partial last round); the
     // controller's owner is tile 0 of the first launch and all rounds vote into the same slot, as in one launch.
-    // Only where the rows of the launch exceed the reach of the address-translation cache (~4 GB, profiles/r04_output_size.txt):
+    // Only where the rows of the launch exceed the ~4 GB footprint knee (a stream through more memory than that
+    // sustains 5-8 % less, whatever the kernel does; profiles/r04_output_size.txt):
     // below it the boundary costs 1-2 % (32 768 envs x 64 steps: 0.887 -> 0.873), beyond it the rounds in step win 3-5 %
-    // (65 536 x 64: 0.750 -> 0.785; the fewer slabs the chip writes at a time, the fewer pages it walks at a time).
+    // (65 536 x 64: 0.750 -> 0.785).
     const int resident = shape.resident_blocks;
     const double rows_bytes = writes_obs ? (double)K * (double)h->E * h->N * (double)(6 + 4 * h->N) * 4.0 : 0.0;
     const bool by_rounds = resident > 0 && shape.num_blocks > resident &&

@@ -779,7 +779,7 @@ def test_a_partial_last_round_does_not_drive_the_common_pace_up(ccx):
 @pytest.mark.parametrize("mode", [0, 2])
 def test_round_by_round_launches_equal_the_oracle(oracle, ccx, mode):
     """A grid of more workgroups than the device holds is launched one round per launch when its rows exceed the reach of
-    the translation cache (ccx_api.hip: run_rollout, KParams::block_base / launch_flags; tunable round_launches: 0 = one
+    the ~4 GB footprint knee (ccx_api.hip: run_rollout, KParams::block_base / launch_flags; tunable round_launches: 0 = one
     launch, 2 = always by rounds): 6001 envs of the C3 geometry in 3001 tiles -- ragged last tile, partial last round -- are
     bit-equal to the oracle either way, and the counters add up over the rounds."""
     g = Golden("g3_c3_dense_simple_distance")
