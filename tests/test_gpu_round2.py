@@ -786,3 +786,18 @@ def test_round_by_round_launches_equal_the_oracle(oracle, ccx, mode):
     c, shape, _, _ = _against_oracle(oracle, ccx, g, E=6001, K=17, seed=35, order=False,
                                      setup=lambda env: env.set_tunable("round_launches", mode))
     assert shape["num_blocks"] > shape["resident_blocks"] > 0
+
+
+def test_round_by_round_launches_of_small_tiles_equal_the_oracle(oracle, ccx):
+    """The same for the bench's geometry (C2: two 64-lane tiles per workgroup, one throttled writer, the pace controller's
+    votes collected over the rounds): 40 003 envs -- 2501 workgroups on 1024 slots, a ragged last tile, a partial last round --
+    with a shuffled move order (the instantiations that are not PLAIN carry block_base too), by rounds and in one launch."""
+    from types import SimpleNamespace
+
+    from collectivecrossing_amd.params import lower_config
+    cfg = _shape_config("c2")
+    g = SimpleNamespace(config=cfg, params=lower_config(cfg), N=8)
+    for mode, order in ((2, False), (2, True), (0, True)):
+        c, shape, _, _ = _against_oracle(oracle, ccx, g, E=40003, K=20, seed=36 + mode, order=order,
+                                         setup=lambda env: env.set_tunable("round_launches", mode))
+        assert shape["num_blocks"] > 2 * shape["resident_blocks"] > 0
