@@ -456,7 +456,7 @@ int ccx_set_reward_table(ccx_handle* h, const double* boarding_per_cell, const d
 int ccx_set_terminated_table(ccx_handle* h, const uint8_t* boarding_per_cell, const uint8_t* exiting_per_cell);
 
 /* Launch shape of the SHORT-LAUNCH kernel (csrc/ccx_step.hip): ccx_step and ccx_rollout calls of at most 16 steps with an
- * action tensor and no move order are CollectiveCrossingEnv.step itself (collectivecrossing.py:161-261) with one workgroup
+ * action tensor (with or without a move order) are CollectiveCrossingEnv.step itself (collectivecrossing.py:161-261) with one workgroup
  * per env tile -- a sim wave plus *row_waves waves that gather the observation rows, one LDS barrier per step, no ring, no
  * pacing.  *ok = 0: this handle's short launches take the rollout kernel (grid too large for the LDS tables).  Tunables:
  * "step_kernel" (0 = always the rollout kernel), "step_rows" (row waves per tile), "step_lanes" (lanes per wave carrying

@@ -68,7 +68,9 @@ def test_bench_line_has_the_contract_fields_and_adds_up():
     assert sec["no_obs"]["us_per_env_step"] * 0.8 < sec["compact_obs"]["us_per_env_step"] < 5
     # round 4: every workload / batch size / duration the builder quotes is in the driver's line
     wl = {(w["workload"], w["envs"]): w for w in sec["workloads"]}
-    assert set(wl) == {("c3", 4096), ("c5_50", 1024), ("c5_64", 1024), ("c2", 1024), ("c2", 2048), ("c2", 16384), ("c2", 32768), ("c2", 65536)}
+    assert set(wl) == {("c3", 4096), ("c5_50", 1024), ("c5_64", 1024), ("c2", 1024), ("c2", 2048), ("c2", 16384), ("c2", 32768), ("c2", 65536),
+                       ("c2", 10000), ("c2", 20000)}
+    assert wl[("c2", 10000)]["frac"] > 0.7 and wl[("c2", 20000)]["frac"] > 0.7      # (round 4 found them at 0.49 / 0.67)
     for key, w in wl.items():
         assert "error" not in w, w
         assert 0.2 < w["frac_wall"] <= w["frac"] * 1.001 < 1.0 and w["timed_launches"] == 10 and w["kernel_ms_per_launch"] > 0, key
