@@ -337,10 +337,13 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
     const double tile_bytes = (double)ew * h->N * (4.0 * (6 + 4 * h->N) + 10.0) + ew;
     s.step_bytes = tile_bytes * tpb * s.resident_blocks;
     auto to_fp = [](double ns) { double v = ns / 10.0 * 256.0; return (uint32_t)(v < 1.0 ? 1.0 : (v > 4.0e9 ? 4.0e9 : v)); };
-    // A batch whose resident tiles cannot even fill the drain rate at a fast 0.45 us per env-step is
-    // bound by the step chain, not by memory: pacing could only cost it (a clock read per step).
-    const bool can_saturate = s.step_bytes / 7000.0 >= 450.0;
+    // A batch whose resident tiles cannot even fill the drain rate at a fast 0.40 us per env-step is
+    // bound by the step chain, not by memory: pacing could only cost it (a clock read per step).  (0.45 us until the end of
+    // round 4: the chain has become faster than that, and C2 batches of 2160 .. 2430 envs ran unpaced INTO the cliff -- 2304
+    // envs at 0.62 of the peak between 0.82 at 2048 and 0.83 at 2500; profiles/r04_small_batch.txt.)
+    const bool can_saturate = s.step_bytes / 7000.0 >= 400.0;
     k.pace_state = (!rows || h->step_pace_ns == -1 || (h->step_pace_ns == 0 && !can_saturate)) ? nullptr : h->pace_state;
+    if (rows) h->ring_when_paced = s.step_bytes / 7000.0 < 550.0;
     k.pace_adapt = (h->step_pace_ns == 0) ? 1u : 0u;
     {   // how many steps make a launch worth pacing (~12 us) / long enough to judge its lateness (~50 us), at the assumed rate
         const double step_ns = s.step_bytes / 6800.0;
@@ -644,6 +647,11 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     // launches the kernel will not pace hand steps to the writer waves through sequence words (ccx_kernels.h: one
     // definition of the launch modes for the host and the kernel)
     kp.hand_flags = ccx::launch_uses_flags(kp.pace_state != nullptr, writes_obs, K, kp.pace_min_k, h->tun_hand2) ? 1u : 0u;
+    // Paced batches whose step period is close to the sim wave's own chain (C2: 2200 .. 3000 envs, 0.41-0.52 us per env-step)
+    // keep the ring too: a barrier per step couples the chain to the writers and such tiles step in 0.46 us instead of 0.40
+    // (2304 envs 0.77 -> 0.83 of the peak, 2816 envs 0.88 -> 0.91; from 3072 envs on there is nothing in it, and saturating
+    // batches want the barrier: DESIGN 3.7; profiles/r04_small_batch.txt)
+    if (h->tun_hand2 == 1 && writes_obs && !small_launch && h->ring_when_paced) kp.hand_flags = 1u;
 #ifdef CCX_LAG_TRACE
     {
         static int* lag_buf = nullptr;
