@@ -296,7 +296,15 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
     s.waves_per_block = tpb;
     s.num_blocks = (tiles + tpb - 1) / tpb;
     s.occ = 1;
-    if (total > 96u * 1024u) {          // tables too big: all-pairs conflict masks instead
+    if (total > 96u * 1024u || h->tun_occ_tables == 0) {          // tables too big (or switched off): all-pairs conflict masks instead
+        s.occ = 0;
+        lay_out(16, tpb, false);
+    }
+    // Single-agent envs: a table of (cells + 1) entries per env, 64 envs per wave -- 73 KB for a 12 x 8 grid, ONE tile per CU:
+    // a batch of more than 64 x CUs envs ran in rounds at twice the time per env-step (17 768 envs: 0.83 us against 0.43 at
+    // 15 800).  An agent alone in its env collides with nobody; the all-pairs masks cost it three VALU ops (+4 % while the
+    // tables fit one round, half the time when they do not: profiles/r04_occ_tables.txt).
+    if (s.occ && glog == 0 && h->tun_occ_tables < 0 && (size_t)s.num_blocks > (lds_cu / total) * (size_t)h->num_cus) {
         s.occ = 0;
         lay_out(16, tpb, false);
     }
@@ -426,7 +434,7 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
         ss.row_waves = h->tun_step_rows > 0 ? h->tun_step_rows
                        : sits <= 6 ? 1 : sits <= 12 ? 2 : sits <= 33 ? 3 : sits <= 45 ? 4 : 5;
         ss.num_blocks = (h->E + sew - 1) / sew;
-        ss.ok = (s.occ && ss.lds_bytes <= 96u * 1024u) ? 1 : 0;
+        ss.ok = ((s.occ || h->tun_occ_tables == 0) && ss.lds_bytes <= 96u * 1024u) ? 1 : 0;   // (the step kernel carries its own, smaller tables)
     }
     return CCX_OK;
 }
@@ -677,16 +685,27 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     // sustains 5-8 % less, whatever the kernel does; profiles/r04_output_size.txt):
     // below it the boundary costs 1-2 % (32 768 envs x 64 steps: 0.887 -> 0.873), beyond it the rounds in step win 3-5 %
     // (65 536 x 64: 0.750 -> 0.785).
+    // The rounds are made EQUAL (R = ceil(blocks / resident) launches of ceil(blocks / R) workgroups, each on a schedule
+    // scaled to its fill): a grid just above a whole number of rounds -- 17 768 envs of C2: 1111 workgroups on 1024 slots --
+    // otherwise spends a full round's time on its last few tiles (0.74-0.77 of the peak where 15 800 envs reach 0.91; balanced:
+    // 0.86-0.87).  That alone is worth the boundary for a paced grid of TWO rounds whose second would be less than 30 % full
+    // (17 000 .. 20 500 envs of C2: +4 .. +12 %; fuller second rounds and grids of three or more rounds: nothing or a loss --
+    // profiles/r04_balanced_rounds.txt).
     const int resident = shape.resident_blocks;
     const double rows_bytes = writes_obs ? (double)K * (double)h->E * h->N * (double)(6 + 4 * h->N) * 4.0 : 0.0;
+    const int n_rounds = resident > 0 ? (shape.num_blocks + resident - 1) / resident : 1;
+    const bool thin_second_round = n_rounds == 2 && (double)(shape.num_blocks - resident) < 0.3 * resident;
+    const bool paced_rows = ccx::launch_is_paced(kp.pace_state != nullptr, writes_obs, K, kp.pace_min_k);
     const bool by_rounds = resident > 0 && shape.num_blocks > resident &&
-                           (h->tun_round_launches >= 2 || (h->tun_round_launches == 1 && rows_bytes > 3.5e9));
+                           (h->tun_round_launches >= 2 ||
+                            (h->tun_round_launches == 1 && (rows_bytes > 3.5e9 || (paced_rows && thin_second_round))));
     hipError_t e = hipSuccess;
     if (by_rounds) {
         ccx::LaunchShape round = shape;
         kp.launch_flags |= ccx::CCX_K_LAUNCH_ROUND;
-        for (int b0 = 0; b0 < shape.num_blocks && e == hipSuccess; b0 += resident) {
-            round.num_blocks = std::min(resident, shape.num_blocks - b0);
+        const int per_round = (shape.num_blocks + n_rounds - 1) / n_rounds;
+        for (int b0 = 0; b0 < shape.num_blocks && e == hipSuccess; b0 += per_round) {
+            round.num_blocks = std::min(per_round, shape.num_blocks - b0);
             kp.block_base = (uint32_t)b0;
             e = ccx::launch_rollout(round, h->stream, kp, h->st, h->cell_info, actions,
                                     order, K, auto_reset, h->pool, out, h->counters, policy, actions_out);
@@ -1334,6 +1353,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
         {"pair_rows", &h->tun_pair_rows, -1, 1},
         {"small_shape", &h->tun_small_shape, 0, 1},
         {"round_launches", &h->tun_round_launches, 0, 2},
+        {"occ_tables", &h->tun_occ_tables, -1, 1},
         {"step_kernel", &h->tun_step_kernel, -1, 1},
         {"step_rows", &h->tun_step_rows, 0, 7},
         {"step_lanes", &h->tun_step_lanes, 0, 64},
@@ -1345,7 +1365,7 @@ int ccx_set_tunable(ccx_handle* h, const char* name, int32_t value) {
             *t.slot = value;
             return choose_shape(h);
         }
-    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, hand2, writer_roles, max_launch_steps, pair_rows, small_shape, step_kernel, step_rows, step_lanes)", name);
+    return fail(CCX_EINVAL, "unknown tunable '%s' (pace_phase, tile_map, hand2, writer_roles, max_launch_steps, pair_rows, small_shape, round_launches, occ_tables, step_kernel, step_rows, step_lanes)", name);
 }
 
 int ccx_get_step_pace(ccx_handle* h, float* ns_per_env_step) {

@@ -73,6 +73,7 @@ struct ccx_handle {
     int tun_step_rows = 0, tun_step_lanes = 0;                  // short-launch kernel: row waves per tile (0 = default), lanes per wave carrying agents (0 = default)
     ccx::StepShape step_shape{};
     bool ring_when_paced = false;                               // paced launches of this shape hand steps over through the sequence-word ring (step period close to the sim chain)
+    int tun_occ_tables = -1;                                    // 0: the rollout kernel compares all pairs of an env instead of keeping LDS occupancy tables (-1: the library's choice)
     int tun_round_launches = 1;                                 // 1: a grid of several rounds of workgroups is launched round by round when its rows exceed ~3.5 GB, 2: always, 0: one launch
     int tun_small_shape = 1;                                    // 1: launches without observation rows take their own launch shape (shape_small), 0: the rows shape
     ccx::LaunchShape shape{};                                   // launches that write observation rows

@@ -517,8 +517,8 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
            hand2=st.sampled_from([1, 1, 0, 2]), full_tiles=st.booleans(), eps=st.sampled_from([0.0, 0.0, 0.1, 0.5, 1.0]),
            mt=st.sampled_from([False, False, True]), pair_rows=st.sampled_from([-1, -1, 0]),
            step=st.sampled_from([(-1, 0, 0), (-1, 0, 0), (0, 0, 0), (1, 1, 0), (1, 2, 64), (1, 3, 16), (1, 5, 8), (1, 7, 0)]),
-           small_shape=st.sampled_from([1, 1, 0]), tables=st.sampled_from([0, 0, 0, 1, 2, 3]))
-    def run(cfg, seed, E, K, mode, compact, writers, roles, hand2, full_tiles, eps, mt, pair_rows, step, small_shape, tables):
+           small_shape=st.sampled_from([1, 1, 0]), tables=st.sampled_from([0, 0, 0, 1, 2, 3]), occ=st.sampled_from([-1, -1, -1, 0]))
+    def run(cfg, seed, E, K, mode, compact, writers, roles, hand2, full_tiles, eps, mt, pair_rows, step, small_shape, tables, occ):
         p = lower_config(cfg)
         N = p.num_boarding + p.num_exiting
         rng = np.random.default_rng(seed)
@@ -539,6 +539,7 @@ def test_arbitrary_valid_configs_kernel_equals_oracle(oracle, ccx):
             env.set_tunable("step_rows", step[1])
             env.set_tunable("step_lanes", step[2])
             env.set_tunable("small_shape", small_shape)
+            env.set_tunable("occ_tables", occ)            # (0: the all-pairs instantiations of the rollout kernel whatever the grid)
             if tables and (cfg.width + 3) * (cfg.height + 3) <= 1200:
                 shape = (cfg.height + 1, cfg.width + 1)
                 rew = (rng.normal(size=shape), rng.normal(size=shape)) if tables & 1 else None

@@ -801,3 +801,23 @@ def test_round_by_round_launches_of_small_tiles_equal_the_oracle(oracle, ccx):
         c, shape, _, _ = _against_oracle(oracle, ccx, g, E=40003, K=20, seed=36 + mode, order=order,
                                          setup=lambda env: env.set_tunable("round_launches", mode))
         assert shape["num_blocks"] > 2 * shape["resident_blocks"] > 0
+
+
+def test_large_batches_of_single_agent_envs_run_in_one_round_and_equal_the_oracle(oracle, ccx):
+    """One agent per env, 64 envs per wavefront: the LDS occupancy tables (one per env) allowed ONE tile per CU, so more than
+    64 x CUs envs ran in rounds -- 17 768 envs at twice the time per env-step of 15 800 (profiles/r04_cliff_scan.txt).  Such a
+    batch now takes the all-pairs instantiations (an agent alone in its env collides with nobody): everything is resident, the
+    trajectory is the oracle's, and an explicit request keeps either path (tunable occ_tables)."""
+    from types import SimpleNamespace
+
+    from collectivecrossing_amd import configs as C
+    from collectivecrossing_amd.params import lower_config
+    cfg = C.CollectiveCrossingConfig(width=12, height=8, division_y=4, tram_door_left=5, tram_door_right=7, tram_length=9,
+                                     num_boarding_agents=1, num_exiting_agents=0, exiting_destination_area_y=0,
+                                     boarding_destination_area_y=8, truncated_config=C.MaxStepsTruncatedConfig(max_steps=30))
+    g = SimpleNamespace(config=cfg, params=lower_config(cfg), N=1)
+    c, shape, _, _ = _against_oracle(oracle, ccx, g, E=20011, K=40, seed=41, order=False)
+    assert shape["num_blocks"] == shape["resident_blocks"] > 256
+    c1, shape1, _, _ = _against_oracle(oracle, ccx, g, E=20011, K=40, seed=41, order=False,
+                                       setup=lambda env: env.set_tunable("occ_tables", 1))
+    assert shape1["num_blocks"] > shape1["resident_blocks"] and c1 == c
