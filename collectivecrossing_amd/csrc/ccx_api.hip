@@ -415,9 +415,10 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
 
     if (!rows) return CCX_OK;
     // Short launches (<= 16 steps, ccx_step.hip): a workgroup = one tile = a sim wave + row waves, as many tiles as the
-    // batch allows up to ~2 per CU (a one-step launch is bound by how fast its waves are dispatched and drained: with the row
-    // waves' table words preloaded, 512 tiles of 64 lanes + 2 row waves step C2's 4096 envs in 3.64 us, 1024 tiles of 32 + 1
-    // in 3.72; profiles/r04_step_k1_shapes_*.txt), never more envs per wave than the rollout shape (the observation address
+    // batch fills, halved only while there are fewer than one per two CUs (a one-step launch is bound by how fast its waves are
+    // dispatched and drained: with the row waves' table words preloaded, 512 tiles of 64 lanes + 2 row waves step C2's 4096 envs
+    // in 3.64 us, 1024 tiles of 32 + 1 in 3.72; 512 envs: 128 tiles of 32 lanes 3.04 us, 512 tiles of 8 lanes 3.30;
+    // profiles/r04_step_k1_shapes_*.txt, r04_step_scan.txt), never more envs per wave than the rollout shape (the observation address
     // table of a smaller tile is a prefix of the rollout's).  Row waves: enough that one handles <= ~6 store iterations per step
     // (small tiles) or 10-14 (large ones), at most 5 (C5-64: 14.9 us with five, 15.5 with seven).  Grids whose tables exceed
     // the LDS keep the rollout kernel.
@@ -425,7 +426,7 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
         ccx::StepShape& ss = h->step_shape;
         int sew = ew;
         if (h->tun_step_lanes > 0) sew = std::max(1, std::min(ew, h->tun_step_lanes / G));
-        else while (sew > 1 && (h->E + sew - 1) / sew < 2 * h->num_cus) sew >>= 1;   // (two tiles per CU: profiles/r04_step_k1_shapes_*.txt)
+        else while (sew > 1 && (h->E + sew - 1) / sew < h->num_cus / 2) sew >>= 1;   // (profiles/r04_step_scan.txt)
         ss.glog = glog;
         ss.envs_per_wave = sew;
         ss.lds_bytes = ccx::step_lds_bytes(glog, sew, h->N, (int)cells, h->reward_table != nullptr);
