@@ -219,7 +219,7 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
               : small_batch ? 1 : (!rows && writers == 4) ? 1
               : (rows && small_tiles && writers == 1 && tiles <= 8 * h->num_cus) ? 1   // (one round of two-wave workgroups: +1-3 % over pairs, 10 000 .. 16 384 envs of C2)
               : (rows && small_tiles && n4 > 64 * 8 && writers == 3) ? 1
-              : (tiles > 8192 || (small_tiles && tiles >= 512)) ? 2 : 1;
+              : ((tiles > 8192 && writers != 2) || (small_tiles && tiles >= 512)) ? 2 : 1;   // (never two writers in pairs: six-wave workgroups, 16 agents x 36 032 envs ran at 0.47)
     // One round beats two (round 2): a CU holds 16 wavefronts of this kernel (4 per SIMD at its ~100
     // VGPRs).  If the batch needs more than that with the writer count above but fits with ONE writer
     // wave per tile, and that writer's share stays <= 36 store iterations per step, every tile is
@@ -695,7 +695,11 @@ int run_rollout(ccx_handle* h, int K, const uint8_t* actions, const uint8_t* ord
     const int resident = shape.resident_blocks;
     const double rows_bytes = writes_obs ? (double)K * (double)h->E * h->N * (double)(6 + 4 * h->N) * 4.0 : 0.0;
     const int n_rounds = resident > 0 ? (shape.num_blocks + resident - 1) / resident : 1;
-    const bool thin_second_round = n_rounds == 2 && (double)(shape.num_blocks - resident) < 0.3 * resident;
+    // ... and whose tiles can FOLLOW the scaled schedule: a tile with one throttled writer steps in ~1 us at best; where the
+    // common pace is already short (5 agents: 1.3 us for a full device) half-full rounds would be asked for 0.7 us, be late,
+    // vote, and drag the common pace up (N = 5, 17 776 envs: 0.52 of the peak that way; profiles/r04_cliff_scan2.txt)
+    const bool thin_second_round = n_rounds == 2 && (double)(shape.num_blocks - resident) < 0.3 * resident &&
+                                   shape.step_bytes / 7000.0 * (0.5 * shape.num_blocks / resident) >= 1200.0;
     const bool paced_rows = ccx::launch_is_paced(kp.pace_state != nullptr, writes_obs, K, kp.pace_min_k);
     const bool by_rounds = resident > 0 && shape.num_blocks > resident &&
                            (h->tun_round_launches >= 2 ||
