@@ -208,7 +208,7 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
     const long long cap_waves = 16ll * h->num_cus;
     int writers = h->writers > 0 ? h->writers
                   : !rows ? ((tiles > 256 && tiles <= 512) ? 4   // one tile per two SIMDs: five-wave workgroups, one tile each (below)
-                             : glog <= 1 ? 2 : glog <= 4 ? (tiles >= 1024 ? 1 : 2) : (tiles >= 16384 ? 1 : 2))
+                             : glog <= 2 ? 2 : glog <= 4 ? (tiles > 1280 ? 1 : 2) : (tiles >= 1500 ? 1 : 2))
                   : small_batch ? (half_tiles || tiles <= 160 ? 4 : 3)
                   : n4 > 64 * 24 ? 3
                   : small_tiles ? (n4 <= 64 * 8 ? 3 : tiles <= 2 * h->num_cus ? 2 : tiles <= 4 * h->num_cus ? 3 : 1) : 2;
@@ -217,6 +217,11 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
     // 4.43e9 vs 4.23e9 env-steps/s on C2; 3 or 4 per workgroup leave CUs idle and lose 5-10 %)
     int tpb = h->waves_per_block > 0 ? h->waves_per_block
               : small_batch ? 1 : (!rows && writers == 4) ? 1
+              // without rows (profiles/r04_noobs_scan.txt): two-writer tiles NEVER in pairs (six-wave workgroups: 0.45 vs 0.36 us
+              // per env-step from 375 tiles on -- every batch between 2049 and 8191 envs of C2 but 4096), one-writer tiles in
+              // pairs from 1500 tiles on (32 agents, 8192 envs: 1.07 vs 1.31 us)
+              : (!rows && writers == 2) ? 1
+              : (!rows && writers == 1) ? (tiles >= 1500 ? 2 : 1)
               : (rows && small_tiles && writers == 1 && tiles <= 8 * h->num_cus) ? 1   // (one round of two-wave workgroups: +1-3 % over pairs, 10 000 .. 16 384 envs of C2)
               : (rows && small_tiles && n4 > 64 * 8 && writers == 3) ? 1
               : ((tiles > 8192 && writers != 2) || (small_tiles && tiles >= 512)) ? 2 : 1;   // (never two writers in pairs: six-wave workgroups, 16 agents x 36 032 envs ran at 0.47)
