@@ -104,6 +104,7 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
     const int G = 1 << glog;
     const int max_ew = 64 / G;
     int ew;
+    bool drop_tables = false;
     if (h->lanes_per_wave > 0) {
         ew = h->lanes_per_wave / G;
     } else {
@@ -125,7 +126,12 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
             return up(cells_ * 8u) + (h->reward_table ? up(cells_ * 16u) : 0u) +
                    up(ccx::tile_head_bytes(16) + 7u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) + up((units_ + 2u) * 2u);
         };
-        if (need(1) <= 96u * 1024u)
+        // Single-agent envs (one table PER ENV, 64 envs per wave): where full tiles with tables would not even be resident
+        // together, the tables go instead of the lanes (below: drop_tables) -- an agent alone in its env collides with nobody
+        if (glog == 0 && h->tun_occ_tables < 0 && need(ew) > 0 &&
+            (size_t)((h->E + ew - 1) / ew) > (160u * 1024u / need(ew)) * (size_t)h->num_cus)
+            drop_tables = true;
+        if (need(1) <= 96u * 1024u && !drop_tables)
             while (ew > 1 && need(ew) > 96u * 1024u) ew >>= 1;
     }
     // Batches too small to be memory-bound (round 2): one env-step of a tile takes the sim chain's ~0.5 us
@@ -309,7 +315,7 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
     // a batch of more than 64 x CUs envs ran in rounds at twice the time per env-step (17 768 envs: 0.83 us against 0.43 at
     // 15 800).  An agent alone in its env collides with nobody; the all-pairs masks cost it three VALU ops (+4 % while the
     // tables fit one round, half the time when they do not: profiles/r04_occ_tables.txt).
-    if (s.occ && glog == 0 && h->tun_occ_tables < 0 && (size_t)s.num_blocks > (lds_cu / total) * (size_t)h->num_cus) {
+    if (s.occ && glog == 0 && h->tun_occ_tables < 0 && (drop_tables || (size_t)s.num_blocks > (lds_cu / total) * (size_t)h->num_cus)) {
         s.occ = 0;
         lay_out(16, tpb, false);
     }
