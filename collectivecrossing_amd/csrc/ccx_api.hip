@@ -126,13 +126,25 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
             return up(cells_ * 8u) + (h->reward_table ? up(cells_ * 16u) : 0u) +
                    up(ccx::tile_head_bytes(16) + 7u * 1056u + up((size_t)e * 2u * (cells_ + 1u) * msz_)) + up((units_ + 2u) * 2u);
         };
-        // Single-agent envs (one table PER ENV, 64 envs per wave): where full tiles with tables would not even be resident
-        // together, the tables go instead of the lanes (below: drop_tables) -- an agent alone in its env collides with nobody
-        if (glog == 0 && h->tun_occ_tables < 0 && need(ew) > 0 &&
-            (size_t)((h->E + ew - 1) / ew) > (160u * 1024u / need(ew)) * (size_t)h->num_cus)
-            drop_tables = true;
-        if (need(1) <= 96u * 1024u && !drop_tables)
-            while (ew > 1 && need(ew) > 96u * 1024u) ew >>= 1;
+        // The tables cost LDS -- one per env, (cells + 1) x 8 bytes -- and LDS is what bounds how many tiles a CU holds: a 24 x 16
+        // grid keeps three 8-env tiles per CU where five fit without tables, a 64 x 48 grid ONE two-env tile; single-agent envs
+        // on 12 x 8 one 64-env tile.  A batch that needs more ROUNDS because of them pays a round's time for each (64 x 48,
+        // 8 agents: 0.18-0.24 of the HBM peak with tables, 0.51-0.63 without; 24 x 16, 16 384 envs: 0.69 vs 0.93;
+        // profiles/r04_big_grid_scan.txt).  The all-pairs masks cost the sim chain ~5.5 % per lane of the group (8 agents:
+        // 0.47 vs 0.34 us per env-step; 32: 2.8 x).  For groups of <= 8 lanes the tables go (and the tile keeps its lanes)
+        // where the rounds saved outweigh that.
+        const int ew_fit = [&] { int e = ew; if (need(1) <= 96u * 1024u) while (e > 1 && need(e) > 96u * 1024u) e >>= 1; return e; }();
+        if (glog <= 3 && h->tun_occ_tables < 0) {
+            auto rounds = [&](int e, size_t bytes_per_tile) {
+                const size_t per_cu = std::max<size_t>(1, std::min<size_t>(160u * 1024u / std::max<size_t>(bytes_per_tile, 1), 5u));
+                const size_t tiles_ = (size_t)(h->E + e - 1) / (size_t)e;
+                return (tiles_ + per_cu * h->num_cus - 1) / (per_cu * h->num_cus);
+            };
+            const size_t with_tables = rounds(ew_fit, need(ew_fit));
+            const size_t without = rounds(ew, need(ew) - up((size_t)ew * 2u * (cells_ + 1u) * msz_));
+            if ((double)without * (1.0 + 0.055 * G) < (double)with_tables) drop_tables = true;
+        }
+        if (!drop_tables) ew = ew_fit;
     }
     // Batches too small to be memory-bound (round 2): one env-step of a tile takes the sim chain's ~0.5 us
     // whatever the tile holds, so what counts is that no writer wave takes longer than that and that every
@@ -295,19 +307,19 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
     // the limit and two steps' stores back to back cost it 5-7 %: tunable pair_rows = 1 forces it for every small batch)
     if (small_batch && writers >= 2 && (h->tun_pair_rows == 1 || (h->tun_pair_rows < 0 && half_tiles))) {
         wsw = 2;
-        lay_out(16, tpb, true);
+        lay_out(16, tpb, !drop_tables);
         if (total > 96u * 1024u) wsw = 1;
     }
-    lay_out(16, tpb, true);
+    lay_out(16, tpb, !drop_tables);
     if (h->waves_per_block == 0)        // a default never costs the occupancy tables their LDS
         while (tpb > 1 && total > 96u * 1024u) {
             --tpb;
-            lay_out(16, tpb, true);
+            lay_out(16, tpb, !drop_tables);
         }
     s.waves_per_block = tpb;
     s.num_blocks = (tiles + tpb - 1) / tpb;
     s.occ = 1;
-    if (total > 96u * 1024u || h->tun_occ_tables == 0) {          // tables too big (or switched off): all-pairs conflict masks instead
+    if (total > 96u * 1024u || h->tun_occ_tables == 0 || drop_tables) {          // tables too big (or switched off, or given up for residency): all-pairs conflict masks instead
         s.occ = 0;
         lay_out(16, tpb, false);
     }
@@ -315,7 +327,7 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
     // a batch of more than 64 x CUs envs ran in rounds at twice the time per env-step (17 768 envs: 0.83 us against 0.43 at
     // 15 800).  An agent alone in its env collides with nobody; the all-pairs masks cost it three VALU ops (+4 % while the
     // tables fit one round, half the time when they do not: profiles/r04_occ_tables.txt).
-    if (s.occ && glog == 0 && h->tun_occ_tables < 0 && (drop_tables || (size_t)s.num_blocks > (lds_cu / total) * (size_t)h->num_cus)) {
+    if (s.occ && h->tun_occ_tables < 0 && (drop_tables || (glog == 0 && (size_t)s.num_blocks > (lds_cu / total) * (size_t)h->num_cus))) {
         s.occ = 0;
         lay_out(16, tpb, false);
     }
