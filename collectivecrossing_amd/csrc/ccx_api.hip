@@ -303,6 +303,41 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
         tile_stride = up16(off_occ + (with_occ ? occ_bytes : 0));
         total = off_tiles + (size_t)tiles_pb * tile_stride + table;
     };
+    // A CELL table that fills much of the LDS by itself (64 x 48: 27 KB, 80 x 60: 39 KB, 100 x 100: 85 KB -- one per
+    // workgroup) limits the workgroups per CU, and then the tiles per workgroup decide how much of the batch is resident:
+    // 100 x 100, 8 agents, 16 384 envs in one-tile workgroups = 256 tiles at a time, 0.35 of the HBM peak and 3.9 us per
+    // env-step without rows; four one-writer tiles per workgroup = 1024 at a time, 0.85 and 0.90 us
+    // (profiles/r04_big_grid_scan.txt).  Among the rule's own (writers, tiles) and the fuller workgroups -- the same writers
+    // with more tiles, ONE writer with up to four -- the one that needs the fewest rounds is taken (ties: the rule's writers,
+    // then fewer tiles per workgroup).
+    if (h->writers == 0 && h->waves_per_block == 0 && off_tiles >= 24u * 1024u) {
+        auto rounds_with = [&](int w_, int t_) {
+            const int w_saved = writers;
+            writers = w_;
+            lay_out(16, t_, !drop_tables);
+            if (total > 96u * 1024u) lay_out(16, t_, false);      // (tables that do not fit are not kept: below)
+            writers = w_saved;
+            const size_t blocks = std::max<size_t>(1, std::min<size_t>(lds_cu / std::max<size_t>(total, 1), (size_t)(16 / (t_ * (1 + w_)))));
+            const size_t at_once = blocks * (size_t)t_ * (size_t)h->num_cus;
+            return total > lds_cu ? (size_t)1 << 30 : ((size_t)tiles + at_once - 1) / at_once;
+        };
+        int best_w = writers, best_t = tpb;
+        size_t best = rounds_with(writers, tpb);
+        for (int pass = 0; pass < 2; ++pass) {
+            const int w_ = pass == 0 ? writers : 1;
+            for (int t_ = (pass == 0 ? tpb + 1 : 2); t_ * (1 + w_) <= 8; ++t_) {
+                const size_t r_ = rounds_with(w_, t_);
+                if (r_ < best) { best = r_; best_w = w_; best_t = t_; }
+            }
+        }
+        writers = best_w;
+        tpb = best_t;
+        s.waves_per_block = tpb;
+        s.writers = writers;
+        s.num_blocks = (tiles + tpb - 1) / tpb;
+        s.store_throttle = h->store_throttle > 0 ? h->store_throttle
+                           : (h->store_throttle == 0 && small_tiles && writers == 1) ? (h->step_pace_ns == -1 ? 16 : 48) : 0;
+    }
     // (by default only with half tiles, <= 1024 envs of the C2 geometry: +3 % there; at 2048 envs the unpaced write stream is
     // the limit and two steps' stores back to back cost it 5-7 %: tunable pair_rows = 1 forces it for every small batch)
     if (small_batch && writers >= 2 && (h->tun_pair_rows == 1 || (h->tun_pair_rows < 0 && half_tiles))) {
@@ -310,8 +345,10 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
         lay_out(16, tpb, !drop_tables);
         if (total > 96u * 1024u) wsw = 1;
     }
+    lay_out(16, 1, !drop_tables);
+    const bool tables_can_fit = total <= 96u * 1024u;    // (with one tile per workgroup; a 100 x 100 grid: never)
     lay_out(16, tpb, !drop_tables);
-    if (h->waves_per_block == 0)        // a default never costs the occupancy tables their LDS
+    if (h->waves_per_block == 0 && tables_can_fit)        // a default never costs the occupancy tables their LDS
         while (tpb > 1 && total > 96u * 1024u) {
             --tpb;
             lay_out(16, tpb, !drop_tables);
