@@ -131,10 +131,11 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
         // on 12 x 8 one 64-env tile.  A batch that needs more ROUNDS because of them pays a round's time for each (64 x 48,
         // 8 agents: 0.18-0.24 of the HBM peak with tables, 0.51-0.63 without; 24 x 16, 16 384 envs: 0.69 vs 0.93;
         // profiles/r04_big_grid_scan.txt).  The all-pairs masks cost the sim chain ~5.5 % per lane of the group (8 agents:
-        // 0.47 vs 0.34 us per env-step; 32: 2.8 x).  For groups of <= 8 lanes the tables go (and the tile keeps its lanes)
-        // where the rounds saved outweigh that.
+        // 0.47 vs 0.34 us per env-step; 32: 2.8 x).  For groups of <= 16 lanes the tables go (and the tile keeps its lanes)
+        // where the rounds saved outweigh that (16 agents on 64 x 48: 0.25-0.35 of the peak with tables -- one 16-lane tile per
+        // CU --, 0.77-0.88 without).
         const int ew_fit = [&] { int e = ew; if (need(1) <= 96u * 1024u) while (e > 1 && need(e) > 96u * 1024u) e >>= 1; return e; }();
-        if (glog <= 3 && h->tun_occ_tables < 0) {
+        if (glog <= 4 && h->tun_occ_tables < 0) {
             auto rounds = [&](int e, size_t bytes_per_tile) {
                 const size_t per_cu = std::max<size_t>(1, std::min<size_t>(160u * 1024u / std::max<size_t>(bytes_per_tile, 1), 5u));
                 const size_t tiles_ = (size_t)(h->E + e - 1) / (size_t)e;
@@ -265,6 +266,12 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
             } else {
                 writers = 1;
             }
+        } else if (writers == 2 && tiles >= 8192 && n4 <= 64 * 36) {
+            // the two-writer class (13-24 store iterations per tile: 12-20 agents) in many rounds: the same one writer, in
+            // pairs (20 agents on 24 x 16, 32 768 envs: 0.74 vs 0.42 of the peak; 40 x 30: 0.70 vs 0.65;
+            // profiles/r04_big_grid_scan.txt)
+            writers = 1;
+            tpb = 2;
         }
     }
     while (tpb > 1 && tpb * (1 + writers) > 8) --tpb;   // <= 512 threads per workgroup

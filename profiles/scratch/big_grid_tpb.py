@@ -19,7 +19,8 @@ def _init(self, *a, **k):
 
 
 BatchedCollectiveCrossing.__init__ = _init
-for (w, h, n) in ((100, 100, 8), (80, 60, 8), (100, 100, 20)):
+GRIDS = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]] or [(100, 100, 8), (80, 60, 8), (100, 100, 20)]
+for (w, h, n) in GRIDS:
     c = b.cfg(w, h, n)
     for mode in ("rows", "noobs"):
         for E in (4096, 16384, 32768):
