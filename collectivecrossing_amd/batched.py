@@ -280,8 +280,24 @@ class BatchedCollectiveCrossing:
         check(self._lib.ccx_step(self._h, a.data_ptr(), None if o is None else o.data_ptr(), cached[1]))
         return cached[2]
 
+    def rows_alignment(self) -> int:
+        """Smallest batch-size multiple for which one env-step's slab of observation rows ([E][N][L] floats) is a whole number
+        of 128-byte lines.  A batch that is not such a multiple still gives bit-identical results, but every step's slab then
+        starts mid-line and the row stores take the region-relative layout: 15-30 % slower for narrow rows, half the rate for
+        wide ones (50 agents: 0.47 instead of 0.85 of the HBM peak)."""
+        row_bytes, m = self.num_agents * self.obs_len * 4, 1
+        while (row_bytes * m) % 128:
+            m *= 2
+        return m
+
     def alloc_rollout(self, num_steps: int, want_obs: bool = True, want_compact: bool = False) -> RolloutResult:
         K, E, N = num_steps, self.num_envs, self.num_agents
+        if want_obs and K >= 32 and E % self.rows_alignment() and not getattr(self, "_warned_alignment", False):
+            import warnings
+            self._warned_alignment = True
+            warnings.warn(f"{E} envs x {N} agents: a step's observation rows are not a whole number of 128-byte lines; rollouts with "
+                          f"rows run faster with a batch size that is a multiple of {self.rows_alignment()} (results are identical)",
+                          RuntimeWarning, stacklevel=2)
         return RolloutResult(self._new((K, E, N, self.obs_len), torch.float32) if want_obs else None,
                              self._new((K, E, N), torch.float64), self._new((K, E, N), torch.uint8),
                              self._new((K, E), torch.uint8),
