@@ -283,8 +283,8 @@ class BatchedCollectiveCrossing:
     def rows_alignment(self) -> int:
         """Smallest batch-size multiple for which one env-step's slab of observation rows ([E][N][L] floats) is a whole number
         of 128-byte lines.  A batch that is not such a multiple still gives bit-identical results, but every step's slab then
-        starts mid-line and the row stores take the region-relative layout: 15-30 % slower for narrow rows, half the rate for
-        wide ones (50 agents: 0.47 instead of 0.85 of the HBM peak)."""
+        starts somewhere else within a line: wide rows (about 40 agents and more) take a per-step layout and lose ~5 %, narrow
+        ones keep the region-relative layout and lose 10-30 %."""
         row_bytes, m = self.num_agents * self.obs_len * 4, 1
         while (row_bytes * m) % 128:
             m *= 2

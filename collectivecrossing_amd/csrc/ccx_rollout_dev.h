@@ -328,7 +328,9 @@ __device__ __forceinline__ KernargTailC& rollout_kernarg_tail() {
 //        loop is compiled without those branches (12 % fewer cycles per env-step on the sim chain).
 //   OUTM 0 = no trajectory outputs, 1 = outputs, 2 = outputs whose tile regions do not begin / end on 128-byte
 //        lines (edge iterations; a separate instantiation because the single-writer C2 path loses 4-5 %
-//        to ANY extra instruction in its store loop, even a never-taken branch)
+//        to ANY extra instruction in its store loop, even a never-taken branch), 3 = the same when the slab STRIDE is not a
+//        multiple of 128 bytes either (batch sizes off rows_alignment(): the region's place in its line moves from step to step
+//        and the layout is worked out per step; its own instantiation so that 2 -- C5-50's bench kernel -- stays as it was)
 //
 // The kernel proper.  A CU must hold 16 wavefronts of it (4 per SIMD: the launch shapes count on that), i.e. at most
 // 128 VGPRs.  The compiler stays below that by itself for the plain instantiations (115-118); those with the policy /

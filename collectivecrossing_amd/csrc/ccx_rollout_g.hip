@@ -1,6 +1,7 @@
 // ccx_rollout_g.hip -- the rollout kernel instantiations of ONE lane-group size (compiled once per CCX_GLOG = 0..6:
 // csrc/Makefile) and their host-side launch.  See ccx_rollout_dev.h / ccx_rollout_body.inc for the kernel itself.
 #include "ccx_rollout_dev.h"
+#include <algorithm>
 
 #ifndef CCX_GLOG
 #error "compile with -DCCX_GLOG=0..6"
@@ -37,7 +38,13 @@ static hipError_t launch_rollout_g(const LaunchShape& ls, hipStream_t stream, co
     // edge iterations: the tile regions of the observation output share 128-byte lines with their neighbours
     const size_t tile_region = (size_t)p.EW * p.N * (6 + 4 * p.N) * 4u, slab = (size_t)p.E * p.N * (6 + 4 * p.N) * 4u;
     const bool edges = out.obs && (((tile_region | slab) & 127u) != 0 || (reinterpret_cast<uintptr_t>(out.obs) & 127u) != 0);
-    const int outm = want_out ? (edges ? 2 : 1) : 0;
+    // (3: the slab stride itself is not a multiple of 128 bytes -- `lead` per step, ccx_rollout_body.inc: VARLEAD -- and a row
+    //  writer has more store iterations than it caches source addresses for: 50 agents x 532 envs 0.50 -> 0.88 of the peak.  Narrow
+    //  rows, all of whose iterations are register-cached, are faster with the launch-wide layout: 3 agents 0.28 vs 0.19.)
+    const int row_writers = std::max(1, ls.writers - ((p.writer0_small && ls.writers > 1) ? 1 : 0));
+    const int its = ((p.units_per_wave >> (pair ? 1 : 0)) + 63) / 64;
+    const bool long_rows = (its + row_writers - 1) / row_writers > kFastObsIters;
+    const int outm = want_out ? (edges ? ((slab & 127u) != 0 && long_rows ? 3 : 2) : 1) : 0;
     const bool plain = order == nullptr && policy == 0 && p.user_tables == 0u;   // (user reward / terminated tables: the general instantiations)
 #define CCX_GO2(P_, O_, C_)                                                                                  \
     return plain ? launch_rollout_v<GLOG, P_, O_, C_, true>(ls, stream, p, st, cell_info, actions, order, K, \
@@ -46,6 +53,7 @@ static hipError_t launch_rollout_g(const LaunchShape& ls, hipStream_t stream, co
                                                              auto_reset, pool, out, counters, policy, actions_out)
 #define CCX_GO(P_, C_)                \
     switch (outm) {                   \
+    case 3: CCX_GO2(P_, 3, C_);       \
     case 2: CCX_GO2(P_, 2, C_);       \
     case 1: CCX_GO2(P_, 1, C_);       \
     default: CCX_GO2(P_, 0, C_);      \
