@@ -493,7 +493,9 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
         ccx::StepShape& ss = h->step_shape;
         int sew = ew;
         if (h->tun_step_lanes > 0) sew = std::max(1, std::min(ew, h->tun_step_lanes / G));
-        else while (sew > 1 && (h->E + sew - 1) / sew < h->num_cus / 2) sew >>= 1;   // (profiles/r04_step_scan.txt)
+        else while (sew > 1 && ((h->E + sew - 1) / sew < h->num_cus / 2 ||      // (profiles/r04_step_scan.txt)
+                                ccx::step_lds_bytes(glog, sew, h->N, (int)cells, h->reward_table != nullptr) > 96u * 1024u))
+            sew >>= 1;                                                          // (... and until the tile's tables fit: 40 x 30, 4096 envs took the rollout kernel for 8 KB)
         ss.glog = glog;
         ss.envs_per_wave = sew;
         ss.lds_bytes = ccx::step_lds_bytes(glog, sew, h->N, (int)cells, h->reward_table != nullptr);
@@ -502,7 +504,13 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
         ss.row_waves = h->tun_step_rows > 0 ? h->tun_step_rows
                        : sits <= 6 ? 1 : sits <= 12 ? 2 : sits <= 33 ? 3 : sits <= 45 ? 4 : 5;
         ss.num_blocks = (h->E + sew - 1) / sew;
-        ss.ok = ((s.occ || h->tun_occ_tables == 0) && ss.lds_bytes <= 96u * 1024u) ? 1 : 0;   // (the step kernel carries its own, smaller tables)
+        // (the step kernel carries its own tables whatever the rollout shape does about its; EVERY workgroup stages the cell
+        //  table and zeroes its tables per launch: past ~24 MB of that per step the rollout kernel is the faster one -- 40 x 30,
+        //  4096 envs: 60 MB, 10.2 vs 5.8 us per step; 80 x 60: 113 vs 6.8; profiles/r04_step_big_grid.txt)
+        //  -- or three times the step's rows where those are the larger part: 20 agents on 40 x 30, 4096 envs: 11.9 vs 16.4 us)
+        const double step_rows_bytes = (double)h->E * h->N * (6.0 + 4.0 * h->N) * 4.0;
+        ss.ok = (ss.lds_bytes <= 96u * 1024u &&
+                 (double)ss.num_blocks * (double)ss.lds_bytes <= std::max(24.0e6, 3.0 * step_rows_bytes)) ? 1 : 0;
     }
     return CCX_OK;
 }

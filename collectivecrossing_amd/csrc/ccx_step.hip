@@ -290,7 +290,20 @@ step_kernel(uint8_t* __restrict__ st_base,                      // StateSlab lay
         const uint32_t cw = (uint32_t)lane + 64u * r;
         if (cw < cells) cinfo[cw] = c_first[r];
     }
-    for (uint32_t cw = (uint32_t)lane + 64u * kCellFirst; cw < cells; cw += 64u) cinfo[cw] = cell_info[cw];
+    // (larger grids: eight loads in flight per lane -- one at a time a 64 x 48 table was fifty memory round trips in a row)
+    for (uint32_t cw0 = (uint32_t)lane + 64u * kCellFirst; cw0 < cells; cw0 += 64u * 8u) {
+        unsigned long long c_more[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t cw = cw0 + 64u * (uint32_t)r;
+            c_more[r] = cell_info[cw < cells ? cw : 0u];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t cw = cw0 + 64u * (uint32_t)r;
+            if (cw < cells) cinfo[cw] = c_more[r];
+        }
+    }
     if (has_rtab) {
         double* rt = reinterpret_cast<double*>(smem + off_rtab);
         for (uint32_t t = (uint32_t)lane; t < 2u * cells; t += 64u) rt[t] = reward_table[t];
