@@ -310,6 +310,22 @@ int derive_shape(ccx_handle* h, const bool rows, ccx::LaunchShape& s, ccx::KPara
         tile_stride = up16(off_occ + (with_occ ? occ_bytes : 0));
         total = off_tiles + (size_t)tiles_pb * tile_stride + table;
     };
+    // Tile PAIRS hold fewer tiles per CU than single tiles where the waves are what bounds them (three writers: two
+    // eight-wave workgroups = 4 tiles against five four-wave ones): a batch that fits one round of singles but not of pairs
+    // takes singles (4 agents x 17 776 envs: 0.94 vs 1.40 us per env-step; profiles/r04_rows_456.txt).
+    if (h->writers == 0 && h->waves_per_block == 0 && tpb == 2 && off_tiles < 24u * 1024u) {
+        auto rounds_tpb = [&](int t_) {
+            lay_out(16, t_, !drop_tables);
+            const size_t blocks = std::max<size_t>(1, std::min<size_t>(lds_cu / std::max<size_t>(total, 1), (size_t)(20 / (t_ * (1 + writers)))));
+            const size_t at_once = blocks * (size_t)t_ * (size_t)h->num_cus;
+            return ((size_t)tiles + at_once - 1) / at_once;
+        };
+        if (rounds_tpb(1) < rounds_tpb(2)) {
+            tpb = 1;
+            s.waves_per_block = tpb;
+            s.num_blocks = tiles;
+        }
+    }
     // A CELL table that fills much of the LDS by itself (64 x 48: 27 KB, 80 x 60: 39 KB, 100 x 100: 85 KB -- one per
     // workgroup) limits the workgroups per CU, and then the tiles per workgroup decide how much of the batch is resident:
     // 100 x 100, 8 agents, 16 384 envs in one-tile workgroups = 256 tiles at a time, 0.35 of the HBM peak and 3.9 us per

@@ -19,7 +19,8 @@ def _init(self, *a, **k):
 
 BatchedCollectiveCrossing.__init__ = _init
 NAG = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-cfg = shape_sweep.config_for(NAG)
+import cliff_scan2  # noqa: E402
+cfg = shape_sweep.config_for(NAG) if NAG in (1, 3, 8, 12, 32, 50, 64) else cliff_scan2.config_for(NAG)
 MODE = sys.argv[3] if len(sys.argv) > 3 else "noobs"
 for E in [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (3072, 3424, 3600, 3840, 4000, 4096, 4104, 4200, 4328, 4864, 6160, 8192):
     res = {}
