@@ -500,7 +500,7 @@ def measure_workload(torch, dev, name: str, envs: int, chunk: int, policy: str, 
 # loses 5-8 % once the memory it streams through passes ~4 GB (profiles/r04_output_size.txt)
 SECONDARY_WORKLOADS = [("c3", 0, 500, "random"), ("c5_50", 0, 500, "greedy"), ("c5_64", 0, 500, "greedy"),
                        ("c2", 1024, 500, "random"), ("c2", 2048, 500, "random"), ("c2", 16384, 64, "random"),
-                       ("c2", 32768, 64, "random"), ("c2", 65536, 32, "random"),
+                       ("c2", 32768, 64, "random"), ("c2", 65536, 40, "random"),
                        # two batch sizes BETWEEN the powers of two every launch-shape rule was tuned on (round 4: 10 000 envs sat on a
                        # rule boundary at 0.49 of the peak, 20 000 envs' partial last round drove the pace controller to 0.67)
                        ("c2", 10000, 200, "random"), ("c2", 20000, 100, "random")]
